@@ -1,0 +1,97 @@
+"""The checkers themselves: CPU restatement (oracle/sqoa_oracle.c) and, when built,
+the compiled reference (oracle/_ref) against the committed golden vectors that
+oracle/make_golden.py captured from /root/reference/seqoia.h."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+
+def codecs():
+    out = [po.restatement()]
+    if po.reference() is not None:
+        out.append(po.reference())
+    return out
+
+
+@pytest.mark.parametrize("codec", codecs(), ids=lambda c: c.kind)
+def test_encode_kats(codec, kat_encode):
+    for c in kat_encode:
+        px = np.frombuffer(bytes.fromhex(c["pixels"]), dtype=np.uint8)
+        for mode, key in ((0, "sqoa"), (1, "qoi")):
+            got = codec.encode(px, c["w"], c["h"], c["channels"], mode, c["colorspace"])
+            want = None if c[key] is None else bytes.fromhex(c[key])
+            assert got == want, (c["name"], key)
+
+
+@pytest.mark.parametrize("codec", codecs(), ids=lambda c: c.kind)
+def test_decode_kats(codec, kat_decode):
+    for c in kat_decode:
+        out, d = codec.decode(bytes.fromhex(c["stream"]), c["channels"])
+        if c["pixels"] is None:
+            assert out is None, c["name"]
+        else:
+            assert out is not None and out.tobytes() == bytes.fromhex(c["pixels"]), c["name"]
+            assert [d.width, d.height, d.channels, d.colorspace, d.qoi_compat] == c["desc"], c["name"]
+
+
+def test_decode_rejects_negative_channels():
+    # reference UB (seqoia.h:664 only rejects > 4); the restatement returns NULL
+    px = po.synth(4, 4, 4)
+    enc = po.restatement().encode(px, 4, 4, 4)
+    assert po.restatement().decode(enc, -1)[0] is None
+
+
+def test_synth_digests(synth_digests):
+    """Generator and encoder pinned by FNV digests of reference output."""
+    orc = po.restatement()
+    for c in synth_digests["images"]:
+        px = po.synth(c["w"], c["h"], c["channels"], c["cls"], c["seed"], c["img"])
+        assert f"{po.fnv1a64(px):016x}" == c["raw_fnv"], c
+        s = orc.encode(px, c["w"], c["h"], c["channels"], 0)
+        q = orc.encode(px, c["w"], c["h"], c["channels"], 1)
+        assert (len(s), f"{po.fnv1a64(s):016x}") == (c["sqoa_len"], c["sqoa_fnv"]), c
+        assert (len(q), f"{po.fnv1a64(q):016x}") == (c["qoi_len"], c["qoi_fnv"]), c
+        # round trip (sqoabench.c:448-455) at native and forced channel counts
+        for enc in (s, q):
+            out, d = orc.decode(enc, 0)
+            assert out.tobytes() == px.tobytes()
+            out4, _ = orc.decode(enc, 4)
+            assert out4.reshape(-1, 4)[:, : c["channels"]].tobytes() == px.tobytes()
+
+
+def test_synth_totals(synth_digests):
+    orc = po.restatement()
+    t = synth_digests["totals"]["icon_512_rgb_0_31"]
+    tot = [0, 0]
+    for img in range(t["count"]):
+        px = po.synth(t["w"], t["h"], t["channels"], t["cls"], t["seed"], img)
+        tot[0] += len(orc.encode(px, t["w"], t["h"], t["channels"], 0))
+        tot[1] += len(orc.encode(px, t["w"], t["h"], t["channels"], 1))
+    assert tot == [t["sqoa_total"], t["qoi_total"]]
+
+
+@pytest.mark.skipif(po.reference() is None, reason="compiled reference not built")
+def test_restatement_equals_reference_on_random_streams():
+    """Differential fuzz (successor of sqoafuzz.c:20-32): mutated encoder output and random bodies."""
+    orc, ref = po.restatement(), po.reference()
+    rng = np.random.default_rng(1234)
+    for k in range(400):
+        w, h, ch = int(rng.integers(1, 48)), int(rng.integers(1, 12)), int(rng.integers(1, 7))
+        px = rng.integers(0, 256, size=w * h * (ch if ch < 5 else ch - 2), dtype=np.uint8)
+        if k % 3:
+            px = (px // 64) * 64  # few colours: runs and index hits
+        for mode in (0, 1):
+            a, b = orc.encode(px, w, h, ch, mode), ref.encode(px, w, h, ch, mode)
+            assert a == b
+            if a is None:
+                continue
+            m = bytearray(a)
+            for _ in range(int(rng.integers(0, 6))):
+                m[int(rng.integers(12, len(m)))] = int(rng.integers(0, 256))
+            for oc in (0, 1, 2, 3, 4):
+                (oa, da), (ob, db) = orc.decode(m, oc), ref.decode(m, oc)
+                assert (oa is None) == (ob is None)
+                if oa is not None:
+                    assert oa.tobytes() == ob.tobytes()
+                    assert bytes(da) == bytes(db)
