@@ -1,0 +1,39 @@
+# Builds libsqoa_mi355x.so (gfx950 only) and the test oracle.
+#   make            product library + oracle
+#   make lib        product library only
+#   make tools      C harnesses (sqoabench-style bench, sqoaconv-style converter)
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+CSRC := seqoia_amd/csrc
+OUT := seqoia_amd/lib
+BUILD := build
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+CFLAGS_HOST := -std=gnu99 -O2 -fPIC -Wall -Wextra
+
+KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_runtime.hip
+OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNELS)) $(BUILD)/sqoa_host.o
+
+all: lib oracle
+
+lib: $(OUT)/libsqoa_mi355x.so
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/sqoa_common.h include/sqoa_hip.h include/seqoia.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/sqoa_host.o: $(CSRC)/sqoa_host.c include/sqoa_hip.h include/seqoia.h
+	@mkdir -p $(BUILD)
+	$(CC) $(CFLAGS_HOST) -c $< -o $@
+
+$(OUT)/libsqoa_mi355x.so: $(OBJS)
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf $(BUILD) $(OUT)/*.so
+
+.PHONY: all lib oracle clean

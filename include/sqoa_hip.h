@@ -1,0 +1,109 @@
+/*
+ * sqoa_hip.h -- batch / device-resident entry points of libsqoa_mi355x.so.
+ *
+ * Additive to seqoia.h: nothing here changes a legacy symbol.  The reference
+ * has one image per call on host memory (seqoia.h:363, :374); a GPU needs many
+ * independent images per launch and buffers that stay in HBM, so the batch
+ * boundary is a *plan*: a table of jobs (one per image) uploaded once, then
+ * launched any number of times with no host work besides the launch.
+ *
+ * Plain C ABI: pointers, sizes, ints.  Device addresses are passed as
+ * unsigned long long so the same structs work from cgo / JNI / ctypes.
+ * All functions return 0 on success and a negative SQOA_HIP_E* code otherwise;
+ * sqoa_hip_last_error() gives the text for the calling thread.
+ */
+#ifndef SQOA_HIP_H
+#define SQOA_HIP_H
+
+#include <stddef.h>
+#include "seqoia.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQOA_HIP_ENOGPU   (-1) /* no usable gfx950 device / HIP runtime failure */
+#define SQOA_HIP_EINVAL   (-2)
+#define SQOA_HIP_ENOMEM   (-3)
+#define SQOA_HIP_ELAUNCH  (-4)
+
+/* One image.  Encode: src = pixels (desc.channels layout, reference
+ * seqoia.h:527-542), dst = output slot of at least sqoa_hip_encode_bound()
+ * bytes.  Decode: src = stream of src_size bytes (readable up to the next
+ * multiple of 16), dst = width*height*out_channels bytes, desc.channels = the
+ * `channels` argument of sqoa_decode (0..4), width/height = what the caller
+ * expects (checked against the header). */
+typedef struct {
+    unsigned long long src;      /* device address */
+    unsigned long long dst;      /* device address */
+    unsigned int src_size;       /* decode: stream bytes; encode: ignored */
+    unsigned int dst_cap;        /* bytes available at dst */
+    sqoa_desc desc;
+    unsigned int reserved;
+} sqoa_hip_job;                  /* 40 bytes */
+
+/* Per-image outcome, written by the kernels. */
+typedef struct {
+    int len;                     /* encode: stream bytes; decode: pixel bytes; 0 on failure */
+    int status;                  /* 0 ok, else SQOA_HIP_ST_* */
+    sqoa_desc desc;              /* decode: header fields as sqoa_decode reports them (seqoia.h:673-677) */
+} sqoa_hip_result;               /* 20 bytes */
+
+#define SQOA_HIP_ST_OK        0
+#define SQOA_HIP_ST_BADARG    1  /* the reference would return NULL (seqoia.h:465-480, :662-688, :705-707) */
+#define SQOA_HIP_ST_OVERFLOW  2  /* dst_cap too small */
+#define SQOA_HIP_ST_INTERNAL  3  /* chain wait timed out: a bug, never expected */
+#define SQOA_HIP_ST_SLOWPATH  4  /* decode: stream needs the serial path (REF op etc.); handled in-kernel */
+
+enum { SQOA_HIP_ENCODE = 0, SQOA_HIP_DECODE = 1 };
+
+typedef struct sqoa_hip_plan sqoa_hip_plan;
+
+int sqoa_hip_device_count(void);
+const char *sqoa_hip_last_error(void);
+
+/* Worst-case stream size for one image: w*h*(ch+1)+14+8 (reference
+ * seqoia.h:487-489) plus the start byte the reference forgets (seqoia.h:513),
+ * rounded up to 256 so consecutive slots stay aligned. 0 if desc is invalid. */
+size_t sqoa_hip_encode_bound(const sqoa_desc *desc);
+
+/* Device memory helpers for C callers without another allocator. */
+int sqoa_hip_malloc(int device, size_t bytes, unsigned long long *dptr);
+int sqoa_hip_free(int device, unsigned long long dptr);
+int sqoa_hip_memcpy_h2d(int device, unsigned long long dst, const void *src, size_t bytes);
+int sqoa_hip_memcpy_d2h(int device, void *dst, unsigned long long src, size_t bytes);
+
+/* Plan: uploads the job table, allocates the result table. `kind` is
+ * SQOA_HIP_ENCODE or SQOA_HIP_DECODE. */
+int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_plan **out);
+void sqoa_hip_plan_destroy(sqoa_hip_plan *plan);
+
+/* Replace the job table of an existing plan (n <= the n it was created with):
+ * same batch shape, new buffers.  Synchronises the plan's stream first. */
+int sqoa_hip_plan_update(sqoa_hip_plan *plan, const sqoa_hip_job *jobs, int n);
+
+/* Enqueue the plan's kernels on `stream` (a hipStream_t, NULL = the plan's own
+ * stream).  Asynchronous; no allocation, no host sync: graph-capturable. */
+int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
+
+/* Wait for the plan's stream and copy the n results to host memory. */
+int sqoa_hip_plan_results(sqoa_hip_plan *plan, sqoa_hip_result *out, int n);
+
+/* Launch `iters` times back to back on the plan's own stream between two HIP
+ * events recorded on that stream; *ms_total receives the elapsed time. */
+int sqoa_hip_plan_time(sqoa_hip_plan *plan, int iters, float *ms_total);
+
+/* Synthetic images of SURVEY.md Appendix C written straight into HBM:
+ * n images of w*h*channels bytes, image k = (cls, seed, img0 + k), packed at
+ * dst + k*stride. cls: 0 mixed, 1 icon, 2 photo. */
+int sqoa_hip_synth(int device, unsigned long long dst, size_t stride, unsigned w, unsigned h,
+                   unsigned channels, int cls, unsigned seed, unsigned img0, int n);
+
+/* FNV-1a-64 of n device buffers (one digest per buffer), for size-independent checks. */
+int sqoa_hip_fnv1a64(int device, const unsigned long long *dptrs, const unsigned int *lens, int n,
+                     unsigned long long *digests);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQOA_HIP_H */

@@ -1,0 +1,67 @@
+// sqoa_common.h -- device-side helpers shared by the gfx950 kernels.
+// Wavefront = 64 lanes everywhere; nothing here is portable and nothing needs to be.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sqoa_hip.h"
+
+#define SQOA_DEV __device__ __forceinline__
+
+namespace sqoa {
+
+constexpr uint32_t kPxInit = 0xff000000u;  // (0,0,0,255): reference seqoia.h:521-525, :716-719
+constexpr int kHeader = 14;                // reference seqoia.h:425
+
+SQOA_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// DPP controls (GFX9 encodings)
+constexpr int DPP_ROW_SHR = 0x110;   // + n
+constexpr int DPP_WAVE_SHL1 = 0x130;
+constexpr int DPP_WAVE_SHR1 = 0x138;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+
+// lane i <- v[i-1]; lane 0 <- carry
+SQOA_DEV uint32_t shift_up1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+// lane i <- v[i+1]; lane 63 <- carry
+SQOA_DEV uint32_t shift_down1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, DPP_WAVE_SHL1, 0xf, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes, 6 DPP adds
+SQOA_DEV uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 1, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 2, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 4, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 8, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+
+SQOA_DEV uint32_t bcast_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+SQOA_DEV uint32_t bcast_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// 64-entry colour hash, reference seqoia.h:414-417:  (3r + 5g + 7b + 11a) & 63
+SQOA_DEV uint32_t qoi_hash(uint32_t px) { return __builtin_amdgcn_udot4(px, 0x0b070503u, 0u, false) & 63u; }
+
+// Pixel `idx` of an image whose input stride is `ch` bytes (1..4), as r|g<<8|b<<16|a<<24.
+// Mono keeps r = b = 0 (reference seqoia.h:531-542); no alpha channel -> 255.
+SQOA_DEV uint32_t load_px(const uint8_t* __restrict__ src, uint32_t idx, int ch) {
+    if (ch == 4) return reinterpret_cast<const uint32_t*>(src)[idx];
+    if (ch == 3) {
+        const uint8_t* p = src + (size_t)idx * 3;
+        return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | 0xff000000u;
+    }
+    if (ch == 2) {
+        uint32_t v = reinterpret_cast<const uint16_t*>(src)[idx];
+        return (v & 0xffu) << 8 | (v >> 8) << 24;
+    }
+    return (uint32_t)src[idx] << 8 | 0xff000000u;
+}
+
+}  // namespace sqoa

@@ -1,0 +1,293 @@
+// sqoa_encode.hip -- SQOA / QOI batch encoder for gfx950 (MI355X).
+//
+// Replaces the per-pixel loop of the reference encoder (seqoia.h:530-638) and
+// its tail (seqoia.h:640-649).  Dataflow, per image:
+//
+//   * the image is cut into sub-tiles of 512 pixels; sub-tile j is owned by
+//     wave (j mod W) of the image's workgroup, which walks j, j+W, j+2W, ...
+//   * inside a sub-tile a wave runs 8 steps of 64 pixels, one pixel per lane:
+//     coalesced 256-byte row loads, previous pixel by DPP wave_shr, run
+//     detection by __ballot, op bytes by straight-line integer code, byte
+//     offsets by a 6-step DPP prefix sum, and variable-length compaction by
+//     OR-ing each lane's (<= 9) bytes into a wave-private LDS staging buffer;
+//   * the only state that crosses sub-tiles is (run length, output position
+//     [, colour index]); it travels wave -> wave through tagged 8-byte LDS
+//     words (a decoupled look-back chain inside the workgroup, no barrier);
+//   * finished bytes leave LDS as 16-byte global stores, edges as byte stores.
+//
+// No MFMA: there is no contraction here.  The bound is HBM (4 B/px read,
+// ~2.6 B/px written on the headline batch).
+#include "sqoa_common.h"
+
+namespace sqoa {
+
+constexpr int ENC_S = 8;               // steps per sub-tile
+constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
+constexpr int ENC_STG = 2816;          // staging bytes per wave: 5 B/px * 512 + 9 + spill, multiple of 16
+constexpr uint32_t SPIN_MAX = 1u << 22;
+
+struct EncState {
+    uint32_t bad;  // chain wait timed out (never expected)
+};
+
+// Wait until the 8-byte LDS word carries `tag` in its high half; returns the low half.
+SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& st) {
+    for (uint32_t spin = 0; spin < SPIN_MAX; ++spin) {
+        unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t hi = bcast_first((uint32_t)(v >> 32));
+        if (hi == tag) return bcast_first((uint32_t)v);
+        __builtin_amdgcn_s_sleep(1);
+    }
+    st.bad = 1;
+    return 0;
+}
+
+SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
+    if (lane == 0)
+        __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Op bytes of a pixel that differs from its predecessor (reference seqoia.h:584-635),
+// little-endian in lo (bytes 0-3) / hi (byte 4).  QOI index hits are patched in by the caller.
+template <bool QOI>
+SQOA_DEV void literal_op(uint32_t px, uint32_t pv, bool mono, uint32_t& lo, uint32_t& hi, uint32_t& n) {
+    const int vr = (int8_t)(px - pv);
+    const int vg = (int8_t)((px >> 8) - (pv >> 8));
+    const int vb = (int8_t)((px >> 16) - (pv >> 16));
+    const int va = (int8_t)((px >> 24) - (pv >> 24));
+    const int vg_r = (int8_t)(vr - vg), vg_b = (int8_t)(vb - vg);
+    const uint32_t a1 = (uint32_t)(vg_r + 8), a2 = (uint32_t)(vg_b + 8), a3 = (uint32_t)(vg + 32), a4 = (uint32_t)(va + 16);
+    // -8<=vg_r<8, -8<=vg_b<8, -32<=vg<32, -16<=va<16  (seqoia.h:606-611)
+    const bool luma = (a1 | a2 | (a3 >> 2) | (a4 >> 1)) < 16u;
+    const bool na = va != 0;
+    if (mono) {  // seqoia.h:601-605, :612, :622-633 with col_channels == 1
+        const uint32_t g = (px >> 8) & 255u;
+        if (na) { lo = 0xffu | g << 8 | (px >> 24) << 16; n = 3; }
+        else if (luma) { lo = 0x80u | a3; n = 1; }
+        else { lo = 0xfeu | g << 8; n = 2; }
+        hi = 0;
+        return;
+    }
+    const uint32_t luma_lo = 0x80u | a3 | (a1 << 4 | a2) << 8 | (na ? (0x60u | a4) << 16 : 0u);
+    const uint32_t raw_lo = px << 8 | 0xfeu | (na ? 1u : 0u);
+    if (QOI) {
+        const uint32_t d = (uint32_t)(vr + 2) | (uint32_t)(vg + 2) | (uint32_t)(vb + 2);
+        if (na) { lo = px << 8 | 0xffu; hi = px >> 24; n = 5; }  // seqoia.h:573-580
+        else if (d < 4u) { lo = 0x40u | (uint32_t)(vr + 2) << 4 | (uint32_t)(vg + 2) << 2 | (uint32_t)(vb + 2); hi = 0; n = 1; }
+        else if (luma) { lo = luma_lo; hi = 0; n = 2; }
+        else { lo = raw_lo; hi = 0; n = 4; }
+        return;
+    }
+    lo = luma ? luma_lo : raw_lo;
+    hi = (!luma && na) ? px >> 24 : 0u;
+    n = (luma ? 2u : 4u) + (na ? 1u : 0u);
+}
+
+// Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
+SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, uint8_t* g, int lane) {
+    uint32_t a = (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u;
+    if (a > T) a = T;
+    if ((uint32_t)lane < a) g[lane] = stage[lane];
+    const uint32_t nb = (T - a) >> 4;
+    for (uint32_t u = lane; u < nb; u += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, stage + a + 16u * u, 16);  // unaligned LDS read
+        *reinterpret_cast<uint4*>(g + a + 16u * u) = v;
+    }
+    const uint32_t t0 = a + 16u * nb;
+    if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
+    for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+}
+
+template <int W, bool QOI>
+__global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
+                                                        const int* __restrict__ job_ids,
+                                                        sqoa_hip_result* __restrict__ results) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
+    __shared__ unsigned long long s_run[2][W];
+    __shared__ unsigned long long s_pos[W];
+
+    const int lane = lane_id();
+    const int w = (int)bcast_first(threadIdx.x >> 6);
+    const int jid = job_ids[blockIdx.x];
+    const sqoa_hip_job job = jobs[jid];
+
+    const uint32_t N = job.desc.width * job.desc.height;
+    const int dch = job.desc.channels;
+    const bool mono = dch < 3;
+    const int ch = (mono ? 1 : 3) + ((dch & 1) ? 0 : 1);  // input stride == header byte (seqoia.h:486, :505)
+    const uint8_t* __restrict__ src = reinterpret_cast<const uint8_t*>(job.src);
+    uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(job.dst);
+    const uint32_t hdr_len = QOI ? kHeader : kHeader + 1;
+    const uint32_t nsub = (N + ENC_SUB - 1) / ENC_SUB;
+    constexpr uint32_t M = QOI ? 62u : 512u;  // seqoia.h:411-412
+
+    uint8_t* stage = s_stage[w];
+    if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; }
+    for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    if (w == 0 && (uint32_t)lane < hdr_len) {  // seqoia.h:497-514
+        const uint32_t magic = QOI ? 0x716f6966u : 0x53716f61u;
+        const uint32_t word = lane < 4 ? magic : lane < 8 ? job.desc.width : job.desc.height;
+        uint8_t b = (uint8_t)(word >> (8 * (3 - (lane & 3))));
+        if (lane == 12) b = (uint8_t)ch;
+        if (lane == 13) b = job.desc.colorspace;
+        if (lane == 14) b = 0x31;
+        dst[lane] = b;
+    }
+
+    EncState st{0};
+    const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane
+
+    uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;
+    auto load_sub = [&](uint32_t j, uint32_t (&px)[ENC_S], uint32_t& pb, uint32_t& pa) {
+        const uint32_t base = j * ENC_SUB;
+#pragma unroll
+        for (int s = 0; s < ENC_S; ++s) {
+            const uint32_t idx = base + s * 64 + lane;
+            px[s] = idx < N ? load_px(src, idx, ch) : 0u;
+        }
+        pb = base ? load_px(src, base - 1, ch) : kPxInit;
+        pa = base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u;
+    };
+
+    uint32_t j = w;
+    if (j < nsub) load_sub(j, cur, cur_pb, cur_pa);
+
+    for (; j < nsub; j += W) {
+        uint32_t nxt[ENC_S], nxt_pb = 0, nxt_pa = 0;
+        const bool more = j + W < nsub;
+        if (more) load_sub(j + W, nxt, nxt_pb, nxt_pa);
+
+        const uint32_t base = j * ENC_SUB;
+        const uint32_t pb = bcast_first(cur_pb);
+        const uint32_t pa = bcast_first(cur_pa);
+        const bool has_after = base + ENC_SUB < N;
+        const bool last_sub = j == nsub - 1;
+
+        // ---- pre-pass: equality masks, local run aggregate -----------------------------
+        unsigned long long E[ENC_S];
+        {
+            uint32_t carry = pb;
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                const uint32_t px = cur[s];
+                const uint32_t prev = shift_up1(px, carry);
+                carry = bcast_lane(px, 63);
+                const uint32_t idx = base + s * 64 + lane;
+                E[s] = __ballot(px == prev && idx < N);
+            }
+        }
+        uint32_t trail = 0;
+        bool all_eq = true;
+#pragma unroll
+        for (int s = ENC_S - 1; s >= 0; --s) {
+            if (all_eq) {
+                if (E[s] == ~0ull) trail += 64;
+                else { trail += (uint32_t)__builtin_clzll(~E[s]); all_eq = false; }
+            }
+        }
+        unsigned long long* my_run = &s_run[(j / W) & 1][w];
+        if (!all_eq && !last_sub) chain_post(my_run, j + 1, trail, lane);
+        uint32_t c_in = 0;
+        if (j > 0 && (E[0] & 1ull)) c_in = chain_wait(&s_run[((j - 1) / W) & 1][(j - 1) % W], j, st);
+        if (all_eq && !last_sub) chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
+
+        // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
+        uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
+        uint32_t sbase = 0;    // bytes staged so far
+        uint32_t carry = pb;
+#pragma unroll
+        for (int s = 0; s < ENC_S; ++s) {
+            const uint32_t px = cur[s];
+            const uint32_t prev = shift_up1(px, carry);
+            carry = bcast_lane(px, 63);
+            const uint32_t idx = base + s * 64 + lane;
+            const unsigned long long e = E[s];
+            const bool iseq = (e >> lane) & 1ull;
+
+            uint32_t lo, hi, n;
+            literal_op<QOI>(px, prev, mono, lo, hi, n);
+            if (iseq || idx >= N) { lo = 0; hi = 0; n = 0; }
+            uint32_t b9 = 0;  // 9th byte of a maximal run flush
+
+            if (e != 0ull) {  // some lane continues a run (seqoia.h:544-561, :640-642)
+                const unsigned long long below = ~e & le_mask;
+                const uint32_t k = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) : crun + lane + 1u;
+                const uint32_t r = QOI ? k % M : k & (M - 1u);
+                // is the pixel after lane 63 equal to lane 63's?  (next step's bit 0, or the pixel after the sub-tile)
+                const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == carry);
+                const unsigned long long enext = e >> 1 | nb << 63;
+                const bool fd = iseq && (r == 0u || idx == N - 1u);
+                const bool fl = iseq && !fd && !((enext >> lane) & 1ull);
+                if (fd) { lo = 0xfdu; n = 1; }
+                if (fl) {
+                    if (QOI) { lo = 0xc0u | (r - 1u); n = 1; }
+                    else {
+                        const uint32_t q = ((r - 1u) * 1075u) >> 16;  // (r-1)/61 for r <= 511
+                        const uint32_t last = 0xc0u | (r - 1u - 61u * q);
+                        const unsigned long long fc = 0xfcfcfcfcfcfcfcfcull;
+                        unsigned long long v = q >= 8 ? fc : ((fc & ((1ull << (8 * q)) - 1ull)) | (unsigned long long)last << (8 * q));
+                        lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+                        n = q + 1u;
+                        if (q >= 8) b9 = last;
+                    }
+                }
+            }
+
+            const uint32_t incl = wave_incl_scan(n);
+            const uint32_t o = sbase + incl - n;
+            sbase += bcast_lane(incl, 63);
+
+            const uint32_t sh = (o & 3u) * 8u;
+            const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
+            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
+            if (n) {
+                __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            const bool spill = (o & 3u) + (n > 8u ? 8u : n) > 8u;
+            if (__ballot(spill || n == 9u) != 0ull) {
+                if (spill) __hip_atomic_fetch_or(p + 2, hi >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (n == 9u) {
+                    const uint32_t o9 = o + 8u;
+                    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (o9 & ~3u)), b9 << ((o9 & 3u) * 8u),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            crun = e == ~0ull ? crun + 64u : (uint32_t)__builtin_clzll(~e);
+        }
+
+        // ---- output position from the chain, then drain the staging buffer -------------
+        const uint32_t pos = j == 0 ? hdr_len : chain_wait(&s_pos[(j - 1) % W], j, st);
+        if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
+        flush_stage(stage, sbase, dst + pos, lane);
+        if (last_sub) {  // seqoia.h:644-649
+            const uint32_t end = pos + sbase;
+            if (lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
+            if (lane == 0) results[jid].len = (int)(end + 8u);
+        }
+
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) cur[s] = nxt[s];
+            cur_pb = nxt_pb;
+            cur_pa = nxt_pa;
+        }
+    }
+    if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);
+}
+
+// ---- launch -----------------------------------------------------------------------------
+
+extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                         sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    constexpr int W = 4;
+    if (qoi) return hipErrorNotSupported;
+    hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    return hipGetLastError();
+}
+
+}  // namespace sqoa

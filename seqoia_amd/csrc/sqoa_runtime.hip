@@ -1,0 +1,324 @@
+// sqoa_runtime.hip -- C-ABI batch layer of libsqoa_mi355x.so (include/sqoa_hip.h):
+// plans (job tables resident in HBM), launches, timing with HIP events, device
+// memory helpers, and the synthetic-input / digest utility kernels.
+//
+// The reference has no counterpart for this file: it encodes one image per call
+// on the host (seqoia.h:363, :374).  Argument validation mirrors the
+// reference's own (seqoia.h:465-480) so a job the reference would refuse is
+// reported as SQOA_HIP_ST_BADARG instead of being launched.
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sqoa_common.h"
+
+extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                         sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+                                         sqoa_hip_result* d_results, hipStream_t stream);
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                   \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return fail(code, #expr, e_);   \
+    } while (0)
+
+struct sqoa_hip_plan {
+    int device = 0;
+    int kind = 0;
+    int n = 0, cap = 0;
+    sqoa_hip_job* d_jobs = nullptr;
+    sqoa_hip_result* d_results = nullptr;
+    sqoa_hip_result* d_init = nullptr;  // results as they must read before a launch (BADARG rows pre-filled)
+    int* d_ids = nullptr;               // job indices grouped by kernel variant
+    int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+const char* sqoa_hip_last_error(void) { return g_err; }
+
+int sqoa_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// w*h*(ch+1) + 14 + 8 (reference seqoia.h:487-489) + 1 (start byte, seqoia.h:513)
+static size_t encode_raw_bound(const sqoa_desc* d) {
+    if (!d || d->width == 0 || d->height == 0 || d->channels < 1 || d->channels > 6) return 0;
+    const unsigned ch = (d->channels < 3 ? 1u : 3u) + ((d->channels & 1) ? 0u : 1u);
+    return (size_t)d->width * d->height * (ch + 1) + 14 + 8 + 1;
+}
+
+size_t sqoa_hip_encode_bound(const sqoa_desc* d) { return (encode_raw_bound(d) + 255) & ~(size_t)255; }
+
+int sqoa_hip_malloc(int device, size_t bytes, unsigned long long* dptr) {
+    if (!dptr) return fail(SQOA_HIP_EINVAL, "sqoa_hip_malloc: null out pointer");
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 1), SQOA_HIP_ENOMEM);
+    *dptr = (unsigned long long)(uintptr_t)p;
+    return 0;
+}
+
+int sqoa_hip_free(int device, unsigned long long dptr) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipFree((void*)(uintptr_t)dptr), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+int sqoa_hip_memcpy_h2d(int device, unsigned long long dst, const void* src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipMemcpy((void*)(uintptr_t)dst, src, bytes, hipMemcpyHostToDevice), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+int sqoa_hip_memcpy_d2h(int device, void* dst, unsigned long long src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipMemcpy(dst, (const void*)(uintptr_t)src, bytes, hipMemcpyDeviceToHost), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+// The reference's argument checks for sqoa_encode (seqoia.h:465-480).
+static bool encode_job_ok(const sqoa_hip_job& j) {
+    const sqoa_desc& d = j.desc;
+    if (!j.src || !j.dst || d.width == 0 || d.height == 0 || d.channels < 1 || d.channels > 6 || d.colorspace > 1) return false;
+    if (d.height >= 400000000u / d.width) return false;
+    if (d.channels < 3 && d.qoi_compat) return false;
+    return true;
+}
+
+// Classify jobs, fill the pre-launch result rows and the per-variant id lists, upload all three.
+static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
+    std::vector<sqoa_hip_result> init(n ? n : 1);
+    std::vector<int> ids_a, ids_b;
+    for (int i = 0; i < n; ++i) {
+        memset(&init[i], 0, sizeof(sqoa_hip_result));
+        if (p->kind == SQOA_HIP_ENCODE) {
+            if (!encode_job_ok(jobs[i])) { init[i].status = SQOA_HIP_ST_BADARG; continue; }
+            if (jobs[i].dst_cap < encode_raw_bound(&jobs[i].desc)) { init[i].status = SQOA_HIP_ST_OVERFLOW; continue; }
+            (jobs[i].desc.qoi_compat ? ids_b : ids_a).push_back(i);
+        } else {
+            // sqoa_decode's argument checks (seqoia.h:662-668); header checks happen in the kernel
+            if (!jobs[i].src || !jobs[i].dst || jobs[i].desc.channels > 4 || jobs[i].src_size < 22) {
+                init[i].status = SQOA_HIP_ST_BADARG;
+                continue;
+            }
+            ids_a.push_back(i);
+        }
+    }
+    p->n = n;
+    p->n_sqoa = (int)ids_a.size();
+    p->n_qoi = (int)ids_b.size();
+    ids_a.insert(ids_a.end(), ids_b.begin(), ids_b.end());
+    if (n == 0) return 0;
+    hipError_t e;
+    if ((e = hipMemcpy(p->d_jobs, jobs, sizeof(sqoa_hip_job) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(p->d_init, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (!ids_a.empty() && (e = hipMemcpy(p->d_ids, ids_a.data(), sizeof(int) * ids_a.size(), hipMemcpyHostToDevice)) != hipSuccess))
+        return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
+    return 0;
+}
+
+int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, sqoa_hip_plan** out) {
+    if (!out || !jobs || n < 0 || (kind != SQOA_HIP_ENCODE && kind != SQOA_HIP_DECODE))
+        return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(SQOA_HIP_ENOGPU, "sqoa_hip_plan_create: no usable HIP device (libsqoa_mi355x has no CPU fallback)");
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+
+    sqoa_hip_plan* p = new sqoa_hip_plan;
+    p->device = device;
+    p->kind = kind;
+    p->cap = n;
+    const size_t jb = sizeof(sqoa_hip_job) * (size_t)(n ? n : 1), rb = sizeof(sqoa_hip_result) * (size_t)(n ? n : 1);
+    hipError_t e;
+    if ((e = hipMalloc((void**)&p->d_jobs, jb)) != hipSuccess || (e = hipMalloc((void**)&p->d_results, rb)) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_init, rb)) != hipSuccess || (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&p->ev0)) != hipSuccess ||
+        (e = hipEventCreate(&p->ev1)) != hipSuccess) {
+        sqoa_hip_plan_destroy(p);
+        return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan_create: allocation", e);
+    }
+    int rc = plan_fill(p, jobs, n);
+    if (rc) { sqoa_hip_plan_destroy(p); return rc; }
+    *out = p;
+    return 0;
+}
+
+int sqoa_hip_plan_update(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
+    if (!p || !jobs || n < 0 || n > p->cap) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_update: bad arguments");
+    HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
+    return plan_fill(p, jobs, n);
+}
+
+void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->d_jobs) hipFree(p->d_jobs);
+    if (p->d_results) hipFree(p->d_results);
+    if (p->d_init) hipFree(p->d_init);
+    if (p->d_ids) hipFree(p->d_ids);
+    if (p->ev0) hipEventDestroy(p->ev0);
+    if (p->ev1) hipEventDestroy(p->ev1);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
+    if (!p) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_launch: null plan");
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    if (p->n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
+    if (p->kind == SQOA_HIP_ENCODE) {
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids, p->n_sqoa, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+    } else {
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->d_results, s), SQOA_HIP_ELAUNCH);
+    }
+    return 0;
+}
+
+int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
+    if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");
+    HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
+    if (n) HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+int sqoa_hip_plan_time(sqoa_hip_plan* p, int iters, float* ms_total) {
+    if (!p || iters <= 0 || !ms_total) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_time: bad arguments");
+    HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipEventRecord(p->ev0, p->stream), SQOA_HIP_ELAUNCH);
+    for (int i = 0; i < iters; ++i) {
+        int rc = sqoa_hip_plan_launch(p, nullptr);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(p->ev1, p->stream), SQOA_HIP_ELAUNCH);
+    HIP_TRY(hipEventSynchronize(p->ev1), SQOA_HIP_ELAUNCH);
+    HIP_TRY(hipEventElapsedTime(ms_total, p->ev0, p->ev1), SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- utility kernels ------------------------------------------------------------------------
+
+namespace sqoa {
+
+SQOA_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// SURVEY.md Appendix C generator; one thread per pixel, grid.y = image.
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ dst, size_t stride, uint32_t w, uint32_t h,
+                                                    uint32_t channels, int cls_kind, uint32_t seed, uint32_t img0) {
+    const uint32_t img = img0 + blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const uint32_t x = i % w, y = i / w;
+    const uint32_t s0 = mix32(seed * 0x9E3779B9u + img);
+    const uint32_t n = mix32(s0 ^ (i * 0x85EBCA6Bu + 0x01234567u));
+    const uint32_t m = mix32(s0 ^ ((i >> 1) * 0x85EBCA6Bu + 0x089ABCDEu));
+    uint32_t t, cls;
+    if (cls_kind == 0) {
+        t = mix32(s0 ^ ((y >> 6) * 73856093u) ^ ((x >> 6) * 19349663u));
+        cls = t & 7u;
+    } else if (cls_kind == 1) {
+        t = mix32(s0 ^ ((y >> 5) * 73856093u) ^ ((x >> 5) * 19349663u));
+        if ((t & 15u) < 15u) {
+            const uint32_t k = (t & 15u) < 8u ? 0u : (t >> 4) & 7u;
+            t = mix32(s0 + 0x1000u + k);
+            cls = 0;
+        } else cls = 4;
+    } else { t = s0; cls = 3; }
+    const uint32_t br = (t >> 8) & 255u, bg = (t >> 16) & 255u, bb = t >> 24;
+    uint32_t r, g, b, a = 255;
+    switch (cls) {
+    case 0: r = br; g = bg; b = bb; break;
+    case 1: r = br + (x >> 1); g = bg + (x >> 1) + (y >> 2); b = bb + (y >> 1); break;
+    case 2: r = br + (x >> 1) + (n & 3u) - 2u; g = bg + (x >> 1) + ((n >> 2) & 3u) - 2u; b = bb + (y >> 1) + ((n >> 4) & 3u) - 2u; break;
+    case 3: {
+        const uint32_t dd = (n >> 8) % 25u;
+        r = br + (x >> 1) + dd + ((n >> 16) & 7u) - 16u;
+        g = bg + (y >> 1) + dd - 12u;
+        b = bb + ((x + y) >> 2) + dd + ((n >> 20) & 7u) - 16u;
+        break;
+    }
+    case 4: { const uint32_t q = mix32(t + (m & 15u)); r = q & 255u; g = (q >> 8) & 255u; b = (q >> 16) & 255u; break; }
+    case 5: r = n & 255u; g = (n >> 8) & 255u; b = (n >> 16) & 255u; break;
+    case 6: r = n & 255u; g = (n >> 8) & 255u; b = (n >> 16) & 255u; a = n >> 24; break;
+    default: r = br; g = bg; b = bb; a = 255u - ((x & 63u) << 1); break;
+    }
+    uint8_t* o = dst + (size_t)blockIdx.y * stride + (size_t)i * channels;
+    if (channels == 4) *reinterpret_cast<uint32_t*>(o) = (r & 255u) | (g & 255u) << 8 | (b & 255u) << 16 | a << 24;
+    else { o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
+}
+
+// One lane per buffer: FNV-1a is a serial chain; this is a checking aid, not a hot path.
+__global__ void fnv_kernel(const unsigned long long* __restrict__ ptrs, const uint32_t* __restrict__ lens, int n,
+                           unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(ptrs[i]);
+    unsigned long long h = 0xcbf29ce484222325ull;
+    for (uint32_t k = 0; k < lens[i]; ++k) h = (h ^ p[k]) * 0x100000001b3ull;
+    out[i] = h;
+}
+
+}  // namespace sqoa
+
+extern "C" {
+
+int sqoa_hip_synth(int device, unsigned long long dst, size_t stride, unsigned w, unsigned h, unsigned channels,
+                   int cls, unsigned seed, unsigned img0, int n) {
+    if (!dst || !w || !h || (channels != 3 && channels != 4) || cls < 0 || cls > 2 || n < 0 || (size_t)w * h > 0xffffffffu)
+        return fail(SQOA_HIP_EINVAL, "sqoa_hip_synth: bad arguments");
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    const unsigned blocks = (unsigned)(((size_t)w * h + 255) / 256);
+    for (int done = 0; done < n; done += 32768) {
+        const int m = n - done < 32768 ? n - done : 32768;
+        hipLaunchKernelGGL(sqoa::synth_kernel, dim3(blocks, m), dim3(256), 0, 0, (uint8_t*)(uintptr_t)dst + (size_t)done * stride, stride, w, h,
+                           channels, cls, seed, img0 + done);
+    }
+    HIP_TRY(hipGetLastError(), SQOA_HIP_ELAUNCH);
+    HIP_TRY(hipDeviceSynchronize(), SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+int sqoa_hip_fnv1a64(int device, const unsigned long long* dptrs, const unsigned int* lens, int n, unsigned long long* digests) {
+    if (!dptrs || !lens || !digests || n < 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_fnv1a64: bad arguments");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    unsigned long long *d_p = nullptr, *d_o = nullptr;
+    uint32_t* d_l = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_p, 8 * (size_t)n), SQOA_HIP_ENOMEM);
+    HIP_TRY(hipMalloc((void**)&d_o, 8 * (size_t)n), SQOA_HIP_ENOMEM);
+    HIP_TRY(hipMalloc((void**)&d_l, 4 * (size_t)n), SQOA_HIP_ENOMEM);
+    hipMemcpy(d_p, dptrs, 8 * (size_t)n, hipMemcpyHostToDevice);
+    hipMemcpy(d_l, lens, 4 * (size_t)n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(sqoa::fnv_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, d_p, d_l, n, d_o);
+    hipError_t e = hipMemcpy(digests, d_o, 8 * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(d_p); hipFree(d_o); hipFree(d_l);
+    HIP_TRY(e, SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""GPU parity: the HIP encoder behind the C-ABI vs the oracle, byte for byte.
+
+Every call goes through libsqoa_mi355x.so (seqoia_amd._lib); the oracle
+(oracle/) is only the checker.  Mirrors the reference's own check
+(sqoabench.c:448-455: decode(encode(px)) == px) and adds what the reference
+lacks: byte-identical streams against known answers.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sq():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; refusing to fall back to anything else")
+    import seqoia_amd
+
+    assert seqoia_amd.load().sqoa_hip_device_count() >= 1
+    return seqoia_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle as po
+
+    return po
+
+
+MODES = [0, 1]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_legacy_encode_kats(sq, kat_encode, mode):
+    """sqoa_encode on every golden input captured from the compiled reference (incl. NULL cases)."""
+    key = "qoi" if mode else "sqoa"
+    for c in kat_encode:
+        px = np.frombuffer(bytes.fromhex(c["pixels"]), dtype=np.uint8)
+        got = sq.encode(px, sq.Desc(c["w"], c["h"], c["channels"], c["colorspace"], mode))
+        want = None if c[key] is None else bytes.fromhex(c[key])
+        assert got == want, (c["name"], key)
+
+
+def test_legacy_encode_rejects(sq):
+    """Argument checks of seqoia.h:465-480."""
+    px = np.zeros(64, np.uint8)
+    assert sq.encode(px, sq.Desc(0, 4, 4, 0, 0)) is None
+    assert sq.encode(px, sq.Desc(4, 0, 4, 0, 0)) is None
+    assert sq.encode(px, sq.Desc(4, 4, 0, 0, 0)) is None
+    assert sq.encode(px, sq.Desc(4, 4, 7, 0, 0)) is None
+    assert sq.encode(px, sq.Desc(4, 4, 4, 2, 0)) is None
+    assert sq.encode(px, sq.Desc(20000, 20000, 4, 0, 0)) is None
+    assert sq.encode(px, sq.Desc(4, 4, 1, 0, 1)) is None  # mono + qoi_compat
+    assert sq.encode(px, sq.Desc(4, 4, 2, 0, 1)) is None
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_synth_digests(sq, orc, synth_digests, mode):
+    """Encoder output FNV digests pinned from the compiled reference."""
+    for c in synth_digests["images"]:
+        px = orc.synth(c["w"], c["h"], c["channels"], c["cls"], c["seed"], c["img"])
+        got = sq.encode(px, sq.Desc(c["w"], c["h"], c["channels"], 0, mode))
+        key = "qoi" if mode else "sqoa"
+        assert got is not None and len(got) == c[key + "_len"], c
+        assert f"{orc.fnv1a64(got):016x}" == c[key + "_fnv"], c
+
+
+def test_device_synth_matches_oracle(sq, orc):
+    import torch
+
+    for cls in ("mixed", "icon", "photo"):
+        for (w, h, ch) in [(64, 64, 3), (100, 37, 4), (256, 256, 4)]:
+            t = torch.empty((3, h, w, ch), dtype=torch.uint8, device="cuda")
+            sq.synth(t, cls, seed=5, img0=7)
+            for k in range(3):
+                assert t[k].cpu().numpy().tobytes() == orc.synth(w, h, ch, cls, 5, 7 + k).tobytes(), (cls, w, h, ch, k)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cls,w,h,ch,n", [("mixed", 256, 256, 4, 8), ("icon", 128, 128, 3, 16), ("photo", 200, 150, 3, 4),
+                                           ("mixed", 1024, 1024, 4, 4), ("icon", 512, 512, 3, 4), ("mixed", 333, 77, 4, 5),
+                                           ("icon", 64, 64, 4, 64), ("mixed", 1, 1, 4, 3), ("mixed", 511, 1, 3, 2), ("mixed", 513, 3, 4, 2)])
+def test_batch_encode_matches_oracle(sq, orc, mode, cls, w, h, ch, n):
+    """Batch plan on device-resident synthetic images vs the oracle on the same images."""
+    import torch
+
+    px = torch.empty((n, h, w, ch), dtype=torch.uint8, device="cuda")
+    sq.synth(px, cls, seed=1, img0=0)
+    plan = sq.EncodePlan(px, qoi_compat=mode)
+    plan.launch()
+    res = plan.results()
+    assert (res["status"] == 0).all()
+    streams = plan.streams()
+    o = orc.best()
+    for k in range(n):
+        want = o.encode(orc.synth(w, h, ch, cls, 1, k), w, h, ch, mode)
+        assert streams[k] == want, (cls, w, h, ch, k, len(streams[k]), len(want))
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_batch_encode_random_lowentropy(sq, orc, mode):
+    """Random walks with runs, palette repeats and alpha changes: every op kind at arbitrary alignments."""
+    import torch
+
+    rng = np.random.default_rng(99)
+    o = orc.best()
+    for (w, h, ch) in [(640, 9, 4), (1000, 3, 3), (77, 77, 4), (2048, 2, 4)]:
+        n = 6
+        steps = rng.integers(-3, 4, size=(n, w * h, ch)).astype(np.int64)
+        steps[rng.random((n, w * h)) < 0.5] = 0
+        jump = rng.random((n, w * h)) < 0.05
+        steps[jump] = rng.integers(-128, 128, size=(int(jump.sum()), ch))
+        px = ((np.cumsum(steps, axis=1) + 77) % 256).astype(np.uint8)
+        pal = rng.random((n, w * h)) < 0.1
+        px[pal] = np.array([9, 200, 30, 255][:ch], dtype=np.uint8)
+        # long runs, some longer than 512 and 62
+        for k in range(n):
+            a = int(rng.integers(0, w * h - 1)); b = min(w * h, a + int(rng.integers(1, 1500)))
+            px[k, a:b] = px[k, a]
+        t = torch.from_numpy(px.reshape(n, h, w, ch)).cuda()
+        plan = sq.EncodePlan(t, qoi_compat=mode)
+        plan.launch()
+        assert (plan.results()["status"] == 0).all()
+        for k, s in enumerate(plan.streams()):
+            assert s == o.encode(px[k], w, h, ch, mode), (w, h, ch, k)
+        plan.close()
+
+
+def test_headline_batch_properties(sq, orc, synth_digests):
+    """BASELINE config 2 at reduced count (64 x 1024x1024 RGBA): totals pinned from the reference
+    for images 0-15, plus sampled byte-for-byte checks."""
+    import torch
+
+    n = 64
+    px = torch.empty((n, 1024, 1024, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=1, img0=0)
+    plan = sq.EncodePlan(px, qoi_compat=0)
+    plan.launch()
+    res = plan.results()
+    assert (res["status"] == 0).all()
+    assert int(res["len"][:16].sum()) == synth_digests["totals"]["mixed_1024_rgba_0_15"]["sqoa_total"]
+    o = orc.best()
+    for k in (0, 17, 63):
+        assert plan.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, 0)
+    plan.close()
