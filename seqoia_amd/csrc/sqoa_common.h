@@ -11,6 +11,17 @@
 
 namespace sqoa {
 
+// Device addresses arrive as integers in the job table; tell the compiler they are GLOBAL
+// (address space 1) so it emits global_load/global_store, not flat_*.
+typedef const __attribute__((address_space(1))) uint8_t* gcptr8;
+typedef __attribute__((address_space(1))) uint8_t* gptr8;
+typedef const __attribute__((address_space(1))) uint16_t* gcptr16;
+typedef const __attribute__((address_space(1))) uint32_t* gcptr32;
+typedef __attribute__((address_space(1))) uint32_t* gptr32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4* gptr128;
+typedef const __attribute__((address_space(1))) u32x4* gcptr128;
+
 constexpr uint32_t kPxInit = 0xff000000u;  // (0,0,0,255): reference seqoia.h:521-525, :716-719
 constexpr int kHeader = 14;                // reference seqoia.h:425
 
@@ -51,14 +62,14 @@ SQOA_DEV uint32_t qoi_hash(uint32_t px) { return __builtin_amdgcn_udot4(px, 0x0b
 
 // Pixel `idx` of an image whose input stride is `ch` bytes (1..4), as r|g<<8|b<<16|a<<24.
 // Mono keeps r = b = 0 (reference seqoia.h:531-542); no alpha channel -> 255.
-SQOA_DEV uint32_t load_px(const uint8_t* __restrict__ src, uint32_t idx, int ch) {
-    if (ch == 4) return reinterpret_cast<const uint32_t*>(src)[idx];
+SQOA_DEV uint32_t load_px(gcptr8 src, uint32_t idx, int ch) {
+    if (ch == 4) return ((gcptr32)src)[idx];
     if (ch == 3) {
-        const uint8_t* p = src + (size_t)idx * 3;
+        gcptr8 p = src + (size_t)idx * 3;
         return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | 0xff000000u;
     }
     if (ch == 2) {
-        uint32_t v = reinterpret_cast<const uint16_t*>(src)[idx];
+        uint32_t v = ((gcptr16)src)[idx];
         return (v & 0xffu) << 8 | (v >> 8) << 24;
     }
     return (uint32_t)src[idx] << 8 | 0xff000000u;

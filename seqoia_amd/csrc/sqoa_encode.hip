@@ -84,15 +84,15 @@ SQOA_DEV void literal_op(uint32_t px, uint32_t pv, bool mono, uint32_t& lo, uint
 }
 
 // Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
-SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, uint8_t* g, int lane) {
+SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     uint32_t a = (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u;
     if (a > T) a = T;
     if ((uint32_t)lane < a) g[lane] = stage[lane];
     const uint32_t nb = (T - a) >> 4;
     for (uint32_t u = lane; u < nb; u += 64) {
-        uint4 v;
+        u32x4 v;
         __builtin_memcpy(&v, stage + a + 16u * u, 16);  // unaligned LDS read
-        *reinterpret_cast<uint4*>(g + a + 16u * u) = v;
+        *(gptr128)(g + a + 16u * u) = v;
     }
     const uint32_t t0 = a + 16u * nb;
     if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
@@ -106,6 +106,14 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
+    // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
+    // masks, plus each wave's published end-of-sub-tile table (double-buffered by tile parity)
+    constexpr int QW = QOI ? W : 1;
+    __shared__ uint32_t s_tabw[QW][64];
+    __shared__ uint32_t s_stamp[QW][64];
+    __shared__ unsigned long long s_smask[QW][64];
+    __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
+    __shared__ uint32_t s_tabtag[2][W];
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
@@ -116,14 +124,15 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
     const int dch = job.desc.channels;
     const bool mono = dch < 3;
     const int ch = (mono ? 1 : 3) + ((dch & 1) ? 0 : 1);  // input stride == header byte (seqoia.h:486, :505)
-    const uint8_t* __restrict__ src = reinterpret_cast<const uint8_t*>(job.src);
-    uint8_t* __restrict__ dst = reinterpret_cast<uint8_t*>(job.dst);
+    gcptr8 src = (gcptr8)job.src;
+    gptr8 dst = (gptr8)job.dst;
     const uint32_t hdr_len = QOI ? kHeader : kHeader + 1;
     const uint32_t nsub = (N + ENC_SUB - 1) / ENC_SUB;
     constexpr uint32_t M = QOI ? 62u : 512u;  // seqoia.h:411-412
 
     uint8_t* stage = s_stage[w];
-    if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; }
+    if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
+    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; }
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
@@ -194,6 +203,43 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         if (j > 0 && (E[0] & 1ull)) c_in = chain_wait(&s_run[((j - 1) / W) & 1][(j - 1) % W], j, st);
         if (all_eq && !last_sub) chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
 
+        // ---- QOI: colour index entering this sub-tile, and the one leaving it ---------
+        uint32_t* tabw = s_tabw[w % QW];
+        unsigned long long* smask = s_smask[w % QW];
+        if constexpr (QOI) {
+            uint32_t* stamp = s_stamp[w % QW];
+            uint32_t* pub = s_tabpub[(j / W) & 1][w % QW];
+            // last non-run pixel per slot inside the sub-tile: the table only ever holds the most
+            // recent writer of each slot (hit or miss, seqoia.h:566-571), so it composes by overwrite
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                const bool ne = !((E[s] >> lane) & 1ull) && base + s * 64 + lane < N;
+                if (ne) atomicMax(&stamp[qoi_hash(cur[s])], (uint32_t)(s * 64 + lane + 1));
+            }
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                const bool ne = !((E[s] >> lane) & 1ull) && base + s * 64 + lane < N;
+                const uint32_t h = qoi_hash(cur[s]);
+                if (ne && stamp[h] == (uint32_t)(s * 64 + lane + 1)) pub[h] = cur[s];
+            }
+            uint32_t tin = 0;  // seqoia.h:518
+            if (j > 0) {
+                const uint32_t pp = ((j - 1) / W) & 1, pw = (j - 1) % W;
+                for (uint32_t spin = 0;; ++spin) {
+                    const uint32_t t = __hip_atomic_load(&s_tabtag[pp][pw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (bcast_first(t) == j) break;
+                    if (spin >= SPIN_MAX) { st.bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                tin = s_tabpub[pp][pw % QW][lane];
+            }
+            if (stamp[lane] == 0) pub[lane] = tin;
+            tabw[lane] = tin;
+            stamp[lane] = 0;
+            if (!last_sub && lane == 0)
+                __hip_atomic_store(&s_tabtag[(j / W) & 1][w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t sbase = 0;    // bytes staged so far
@@ -209,6 +255,19 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
             uint32_t lo, hi, n;
             literal_op<QOI>(px, prev, mono, lo, hi, n);
+            if constexpr (QOI) {  // index probe (seqoia.h:563-572), all 64 pixels of the step at once
+                const bool ne = !iseq && idx < N;
+                const uint32_t h = qoi_hash(px);
+                uint32_t cand = tabw[h];  // slot as the previous steps left it
+                if (ne) __hip_atomic_fetch_or(&smask[h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const unsigned long long m = __hip_atomic_load(&smask[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const unsigned long long lower = m & (le_mask >> 1);  // earlier lanes of this step on my slot
+                const int from = lower ? 63 - __builtin_clzll(lower) : lane;
+                const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
+                if (lower) cand = near;
+                if (ne && (m & ~le_mask) == 0ull) { tabw[h] = px; smask[h] = 0; }  // last writer of the slot in this step
+                if (ne && cand == px) { lo = h; hi = 0; n = 1; }
+            }
             if (iseq || idx >= N) { lo = 0; hi = 0; n = 0; }
             uint32_t b9 = 0;  // 9th byte of a maximal run flush
 
@@ -285,8 +344,8 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     constexpr int W = 4;
-    if (qoi) return hipErrorNotSupported;
-    hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     return hipGetLastError();
 }
 
