@@ -59,7 +59,7 @@ constexpr int SERIAL_LANES = 64;
 // One image per lane.  table layout [slot][lane] so equal slots across lanes never conflict.
 __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                      const int* __restrict__ job_ids, int n,
-                                                                     sqoa_hip_result* __restrict__ results) {
+                                                                     sqoa_hip_result* __restrict__ results, int only_slowpath) {
     __shared__ uint32_t s_table[128][SERIAL_LANES];
     const int t = threadIdx.x;
     const int slot = blockIdx.x * SERIAL_LANES + t;
@@ -67,6 +67,10 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
     const int jid = job_ids[slot];
     const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
+    if (only_slowpath) {  // second launch: only what the wave-parallel kernel declined
+        if (res->status != SQOA_HIP_ST_SLOWPATH) return;
+        res->status = SQOA_HIP_ST_OK;
+    }
     gcptr8 bytes = (gcptr8)job.src;
     gptr8 out = (gptr8)job.dst;
     const int size = (int)job.src_size;
@@ -138,10 +142,16 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
 
 }  // namespace sqoa
 
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+                                              sqoa_hip_result* d_results, hipStream_t stream);
+
+// Wave-parallel kernel first; whatever it marks SQOA_HIP_ST_SLOWPATH goes through the exact serial kernel.
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+    hipError_t e = sqoa_launch_decode_wave(d_jobs, d_ids, n, d_results, stream);
+    if (e != hipSuccess) return e;
     const int blocks = (n + sqoa::SERIAL_LANES - 1) / sqoa::SERIAL_LANES;
-    hipLaunchKernelGGL(sqoa::decode_serial_kernel, dim3(blocks), dim3(sqoa::SERIAL_LANES), 0, stream, d_jobs, d_ids, n, d_results);
+    hipLaunchKernelGGL(sqoa::decode_serial_kernel, dim3(blocks), dim3(sqoa::SERIAL_LANES), 0, stream, d_jobs, d_ids, n, d_results, 1);
     return hipGetLastError();
 }

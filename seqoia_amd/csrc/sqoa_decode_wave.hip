@@ -1,0 +1,326 @@
+// sqoa_decode_wave.hip -- wave-parallel SQOA/QOI decoder for colour streams (gfx950).
+//
+// Replaces the serial parse of the reference decoder (seqoia.h:722-806) for streams whose ops
+// are RGB/RGBA, LUMA(+ALPHA suffix), RUN/BIGRUN (SQOA) -- i.e. everything the encoder emits.
+// Streams with SQOA_OP_REF, mono streams, QOI streams and 1/2-channel outputs are handed to the
+// exact serial kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
+//
+// Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W):
+//   1. parse: every byte gets a transition function over the 7 parser states
+//      {A: op boundary after an op, N: op boundary where an ALPHA suffix is not allowed,
+//       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes, composition is two
+//      v_perm_b32, so a 64-lane inclusive scan costs 6 DPP steps.  The chunk's total function is
+//      usually constant (the byte stream re-synchronises), so the exit state is published before
+//      the entry state is even known: the chain does not serialise.
+//   2. ops: lanes that sit on an op start decode it from an unaligned 8-byte LDS read (op bytes +
+//      possible ALPHA suffix).  Pixel counts and channel deltas are prefix-summed with DPP;
+//      absolute ops (RGB/RGBA) re-base the sums through __ballot + ds_bpermute.
+//   3. (pixel position, pixel value) entering the chunk arrive through the LDS chain; literal ops
+//      store their pixel directly, runs are expanded cooperatively by the whole wave.
+#include "sqoa_common.h"
+
+namespace sqoa {
+
+constexpr int DEC_S = 8;
+constexpr int DEC_CHUNK = DEC_S * 64;     // stream bytes per chunk
+constexpr int DEC_LDS_DW = 136;           // staged dwords per wave: 512 + 8 look-ahead + 3 misalignment, rounded
+constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
+constexpr uint32_t ID_LO = 0x03020100u, ID_HI = 0x07060504u;  // identity transition function
+
+enum : uint32_t { ST_A = 0, ST_N = 1, ST_X = 6 };
+
+struct Fn { uint32_t lo, hi; };
+
+// (g after f)(s) = g[f(s)]: g is the table, f the selector
+SQOA_DEV Fn compose(Fn g, Fn f) {
+    return Fn{__builtin_amdgcn_perm(g.hi, g.lo, f.lo), __builtin_amdgcn_perm(g.hi, g.lo, f.hi)};
+}
+SQOA_DEV uint32_t apply(Fn f, uint32_t st) { return (uint32_t)(((unsigned long long)f.hi << 32 | f.lo) >> (8u * st)) & 0xffu; }
+
+template <int CTRL, int ROWMASK>
+SQOA_DEV Fn scan_step(Fn F) {
+    Fn P;
+    P.lo = (uint32_t)__builtin_amdgcn_update_dpp((int)ID_LO, (int)F.lo, CTRL, ROWMASK, 0xf, false);
+    P.hi = (uint32_t)__builtin_amdgcn_update_dpp((int)ID_HI, (int)F.hi, CTRL, ROWMASK, 0xf, false);
+    return compose(F, P);
+}
+
+// inclusive composition over the wave: result of lane i = f_i after f_{i-1} after ... after f_0
+SQOA_DEV Fn wave_compose_scan(Fn F) {
+    F = scan_step<DPP_ROW_SHR + 1, 0xf>(F);
+    F = scan_step<DPP_ROW_SHR + 2, 0xf>(F);
+    F = scan_step<DPP_ROW_SHR + 4, 0xf>(F);
+    F = scan_step<DPP_ROW_SHR + 8, 0xf>(F);
+    F = scan_step<DPP_ROW_BCAST15, 0xa>(F);
+    F = scan_step<DPP_ROW_BCAST31, 0xc>(F);
+    return F;
+}
+
+// bytewise (mod 256) add / sub of four packed channels
+SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
+SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
+
+struct DecShared {
+    unsigned long long parse[2];  // per parity: tag<<32 | exit parser state
+    unsigned long long pos[1];    // tag<<32 | pixel position leaving the chunk
+    unsigned long long px[1];     // tag<<32 | pixel value leaving the chunk
+};
+
+SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const uint32_t* abort_flag, uint32_t& val, uint32_t& bad) {
+    for (uint32_t spin = 0; spin < DEC_SPIN_MAX; ++spin) {
+        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
+        if (bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    bad = 1;
+    return false;
+}
+
+SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
+    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// fill out[p0, p0+cnt) (pixel units) with v; OC = 3 or 4 output channels
+template <int OC>
+SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int lane) {
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        if (OC == 4) ((gptr32)out)[p0 + k] = v;
+        else {
+            gptr8 o = out + (size_t)(p0 + k) * 3;
+            o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
+                                                             const int* __restrict__ job_ids,
+                                                             sqoa_hip_result* __restrict__ results) {
+    __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
+    __shared__ unsigned long long s_parse[2][W];
+    __shared__ unsigned long long s_pos[W];
+    __shared__ unsigned long long s_px[W];
+    __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_path;  // 1 = wave path, 2 = refused
+
+    const int lane = lane_id();
+    const int w = (int)bcast_first(threadIdx.x >> 6);
+    const int jid = job_ids[blockIdx.x];
+    const sqoa_hip_job job = jobs[jid];
+    sqoa_hip_result* res = &results[jid];
+    gcptr8 src = (gcptr8)job.src;
+    gptr8 out = (gptr8)job.dst;
+    const uint32_t size = job.src_size;
+
+    if (threadIdx.x == 0) {
+        s_abort = 0;
+        // header (seqoia.h:672-688): written to the result exactly as sqoa_decode fills *desc
+        const uint32_t magic = (uint32_t)src[0] << 24 | (uint32_t)src[1] << 16 | (uint32_t)src[2] << 8 | src[3];
+        const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+        const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+        const uint32_t hc = src[12], hs = src[13], q = src[14] != 0x31;
+        res->desc.width = hw; res->desc.height = hh; res->desc.channels = (uint8_t)hc;
+        res->desc.colorspace = (uint8_t)hs; res->desc.qoi_compat = (uint8_t)q;
+        const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
+                          (magic == 0x716f6966u && !q) || hh >= 400000000u / hw);
+        uint32_t path = 1;
+        if (!ok) { res->status = SQOA_HIP_ST_BADARG; path = 2; }
+        else {
+            const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
+            if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
+            else if (hc < 3 || q || oc < 3 || (job.src & 3ull)) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }
+        }
+        s_path = path;
+    }
+    if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
+    __syncthreads();
+    if (s_path != 1) return;
+
+    const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+    const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+    const uint32_t hc = src[12];
+    const uint32_t N = bcast_first(hw * hh);
+    const int oc = (int)bcast_first(job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u));
+    const uint32_t p0 = kHeader + 1;            // first chunk byte (SQOA: after the start byte, seqoia.h:705)
+    const uint32_t chunks_len = size - 8;       // seqoia.h:721
+    const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
+    const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
+    const unsigned long long le_mask = (2ull << lane) - 1ull;
+    uint32_t bad = 0;
+
+    uint32_t* lds = s_bytes[w];
+    uint32_t stg[3];
+    auto load_chunk = [&](uint32_t c, uint32_t (&r)[3]) {
+        const uint32_t gs = p0 + c * DEC_CHUNK;
+        const uint32_t d0 = gs >> 2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t d = d0 + lane + 64 * k;
+            r[k] = (k < 2 || lane < DEC_LDS_DW - 128) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+        }
+    };
+
+    uint32_t c = w;
+    if (c < nchunks) load_chunk(c, stg);
+
+    for (; c < nchunks; c += W) {
+        // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
+        lds[lane] = stg[0];
+        lds[lane + 64] = stg[1];
+        if (lane < DEC_LDS_DW - 128) lds[lane + 128] = stg[2];
+        const bool more = c + W < nchunks;
+        if (more) load_chunk(c + W, stg);
+        const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
+        const uint8_t* cb = reinterpret_cast<const uint8_t*>(lds) + (gs & 3u);
+        const bool last_chunk = c == nchunks - 1;
+
+        // ---- 1. parser transition functions, scanned per step; chunk total ------------------
+        Fn fex[DEC_S];       // per lane: composition of all earlier bytes of the step (exclusive)
+        Fn ftot[DEC_S];      // per step: composition of the whole step (uniform)
+        Fn G{ID_LO, ID_HI};
+#pragma unroll
+        for (int s = 0; s < DEC_S; ++s) {
+            const uint32_t i = s * 64 + lane;
+            const uint32_t b0 = cb[i];
+            const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+            const bool sfx = (b0 - 0x60u) < 0x20u;
+            const bool live = gs + i < chunks_len;
+            const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
+            const uint32_t fA = !live ? (uint32_t)ST_X : sfx ? (uint32_t)ST_N : opn;
+            const uint32_t fN = !live ? (uint32_t)ST_X : opn;
+            Fn F = wave_compose_scan(Fn{fA | fN << 8 | 0x02000000u, 0x07060403u});
+            ftot[s] = Fn{bcast_lane(F.lo, 63), bcast_lane(F.hi, 63)};
+            fex[s] = Fn{shift_up1(F.lo, ID_LO), shift_up1(F.hi, ID_HI)};
+            G = compose(ftot[s], G);
+        }
+        // exit state independent of the entry state?  (states A, N, D1..D4; X cannot enter a chunk
+        // that has a successor)  Then publish before waiting.
+        const uint32_t g0 = bcast_first(G.lo) & 0xffu;
+        const bool g_const = bcast_first(G.lo) == g0 * 0x01010101u && (bcast_first(G.hi) & 0xffffu) == g0 * 0x0101u;
+        unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
+        if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
+        uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
+        if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) break;
+        if (!g_const && !last_chunk) post(my_parse, c + 1, apply(Fn{bcast_first(G.lo), bcast_first(G.hi)}, st_in), lane);
+
+        // ---- 2. ops: counts, channel sums, re-basing at absolute ops -------------------------
+        uint32_t meta[DEC_S];   // Prel (20) | cnt (10) << 20 | rgb absolute << 30 | alpha absolute << 31
+        uint32_t vrel[DEC_S];   // pixel value after the op: absolute, or relative to the chunk's entry pixel
+        uint32_t st = st_in, pbase = 0;
+        uint32_t carry_v = 0;           // value entering the step (relative to chunk entry unless absolute)
+        bool carry_rgb_abs = false, carry_a_abs = false;
+        bool ref_seen = false;
+#pragma unroll
+        for (int s = 0; s < DEC_S; ++s) {
+            const uint32_t i = s * 64 + lane;
+            unsigned long long q;
+            __builtin_memcpy(&q, cb + i, 8);  // op byte + up to 4 data bytes + possible ALPHA suffix
+            const uint32_t b0 = (uint32_t)q & 0xffu, b1 = ((uint32_t)q >> 8) & 0xffu;
+            const uint32_t lst = apply(fex[s], st);                 // parser state in front of this byte
+            const bool sfx0 = (b0 - 0x60u) < 0x20u;
+            // op starts: only inside the chunk area (seqoia.h:726), never in states D* / X
+            const bool isop = gs + i < chunks_len && (lst == ST_N || (lst == ST_A && !sfx0));
+            if (__ballot(isop && b0 < 0x60u) != 0ull) { ref_seen = true; break; }  // SQOA_OP_REF: serial path
+            const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+            const uint32_t sb = (uint32_t)(q >> (8u * len)) & 0xffu;  // byte after the op (seqoia.h:777-783)
+            const uint32_t da = (sb - 0x60u) < 0x20u ? ((sb & 31u) - 16u) & 0xffu : 0u;
+            const bool rgbset = isop && b0 >= 0xfeu, aset = isop && b0 == 0xffu;
+            const bool luma = (b0 & 0xc0u) == 0x80u;
+            uint32_t cnt = 0, X = 0, Y = 0, base = 0;
+            if (isop) {
+                cnt = 1;
+                if (b0 >= 0xfeu) {
+                    base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;
+                    Y = aset ? 0u : da << 16;
+                } else if (luma) {  // seqoia.h:761-769
+                    const uint32_t vg = (b0 & 0x3fu) - 32u;
+                    X = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 16;
+                    Y = ((vg - 8u + (b1 & 15u)) & 0xffu) | da << 16;
+                } else {            // RUN / BIGRUN, or a byte 0x60..0x7f in op position (seqoia.h:770-775)
+                    cnt = b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u;
+                    Y = da << 16;
+                }
+            }
+            // prefix sums: pixels, and channel deltas in 16-bit fields (64 * 255 < 65536, no carries)
+            const uint32_t cinc = wave_incl_scan(cnt);
+            const uint32_t SX = wave_incl_scan(X), SY = wave_incl_scan(Y);
+            const uint32_t S8 = __builtin_amdgcn_perm(SY, SX, 0x06040200u);  // r g b a sums, mod 256
+            const uint32_t K8 = sub8(base, S8);                                // absolute op: value minus the sums up to it
+            const unsigned long long mrgb = __ballot(rgbset) & le_mask, ma = __ballot(aset) & le_mask;
+            const int jrgb = mrgb ? 63 - __builtin_clzll(mrgb) : lane, ja = ma ? 63 - __builtin_clzll(ma) : lane;
+            const uint32_t krgb = (uint32_t)__builtin_amdgcn_ds_bpermute(jrgb << 2, (int)K8);
+            const uint32_t ka = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)K8);
+            const uint32_t kb = ((mrgb ? krgb : carry_v) & 0x00ffffffu) | ((ma ? ka : carry_v) & 0xff000000u);
+            const uint32_t v = add8(kb, S8);
+            const bool rgb_abs = mrgb != 0ull || carry_rgb_abs, a_abs = ma != 0ull || carry_a_abs;
+            vrel[s] = v;
+            meta[s] = (pbase + cinc - cnt) | cnt << 20 | (rgb_abs ? 1u << 30 : 0u) | (a_abs ? 1u << 31 : 0u);
+            // carry to the next step
+            const uint32_t tot = bcast_lane(cinc, 63);
+            pbase += tot;  // <= 512 ops * 512 pixels = 2^18 per chunk: fits the 20-bit field
+            carry_v = bcast_lane(v, 63);
+            carry_rgb_abs = carry_rgb_abs || __ballot(rgbset) != 0ull;
+            carry_a_abs = carry_a_abs || __ballot(aset) != 0ull;
+            st = apply(ftot[s], st);
+        }
+        if (ref_seen) {
+            if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
+            break;
+        }
+
+        // ---- 3. entry position / pixel from the chain, publish exits, store ------------------
+        uint32_t pos_in = 0, px_in = kPxInit;
+        if (c > 0) {
+            if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) break;
+            if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) break;
+        }
+        const uint32_t exit_v = ((carry_rgb_abs ? carry_v : add8(px_in, carry_v)) & 0x00ffffffu) |
+                                ((carry_a_abs ? carry_v : add8(px_in, carry_v)) & 0xff000000u);
+        const uint32_t pos_out = pos_in + pbase > N ? N : pos_in + pbase;
+        if (!last_chunk) { post(&s_px[w], c + 1, exit_v, lane); post(&s_pos[w], c + 1, pos_out, lane); }
+
+        if (pos_in < N) {
+#pragma unroll
+            for (int s = 0; s < DEC_S; ++s) {
+                const uint32_t m = meta[s];
+                const uint32_t cnt = (m >> 20) & 0x3ffu;
+                const uint32_t P = pos_in + (m & 0xfffffu);
+                const uint32_t rel = add8(px_in, vrel[s]);
+                const uint32_t v = (((m >> 30) & 1u ? vrel[s] : rel) & 0x00ffffffu) | ((m >> 31 ? vrel[s] : rel) & 0xff000000u);
+                if (cnt == 1u && P < N) {
+                    if (oc == 4) ((gptr32)out)[P] = v;
+                    else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                }
+                unsigned long long runs = __ballot(cnt > 1u && P < N);
+                while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
+                    const int l = __builtin_ctzll(runs);
+                    runs &= runs - 1ull;
+                    const uint32_t rp = bcast_lane(P, l), rv = bcast_lane(v, l);
+                    uint32_t rc = bcast_lane(cnt, l);
+                    if (rp + rc > N) rc = N - rp;
+                    if (oc == 4) fill_pixels<4>(out, rp, rc, rv, lane);
+                    else fill_pixels<3>(out, rp, rc, rv, lane);
+                }
+            }
+        }
+        if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
+            if (pos_out < N) {
+                if (oc == 4) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                else fill_pixels<3>(out, pos_out, N - pos_out, exit_v, lane);
+            }
+            if (lane == 0) res->len = (int)(N * (uint32_t)oc);
+        }
+    }
+    if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+}
+
+}  // namespace sqoa
+
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+                                              sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    constexpr int W = 4;
+    hipLaunchKernelGGL((sqoa::decode_wave_kernel<W>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    return hipGetLastError();
+}
