@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsqoa_mi355x.so")
+# SQOA_LIB: developer override to A/B kernel variants; the default is the in-tree build
+LIB_PATH = os.environ.get("SQOA_LIB") or os.path.join(HERE, "lib", "libsqoa_mi355x.so")
 
 
 class Desc(C.Structure):

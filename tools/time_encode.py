@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Time the encode kernel only (no result checks): for A/B runs of experimental builds via SQOA_LIB."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import seqoia_amd as sq
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=1024); ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--iters", type=int, default=5); ap.add_argument("--cls", default="mixed"); ap.add_argument("--qoi", type=int, default=0)
+ap.add_argument("--channels", type=int, default=4)
+a = ap.parse_args()
+px = torch.empty((a.images, a.size, a.size, a.channels), dtype=torch.uint8, device="cuda")
+sq.synth(px, a.cls, 1, 0)
+enc = sq.EncodePlan(px, qoi_compat=a.qoi)
+enc.launch(); enc.results()
+ms = enc.time(a.iters) / a.iters
+print(f"{os.environ.get('SQOA_LIB','default')} cls={a.cls} encode {ms:.3f} ms/launch  {a.images*a.size*a.size/ms/1e3:.0f} Mpx/s")
