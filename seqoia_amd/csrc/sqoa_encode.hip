@@ -32,16 +32,11 @@ struct EncState {
 
 // Wait until the 8-byte LDS word carries `tag` in its high half; returns the low half.
 SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& st) {
-#ifdef SQOA_DBG_NOCHAIN  // timing experiment only: wrong output
-    return 0;
-#endif
     for (uint32_t spin = 0; spin < SPIN_MAX; ++spin) {
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t hi = bcast_first((uint32_t)(v >> 32));
         if (hi == tag) return bcast_first((uint32_t)v);
-#ifndef SQOA_DBG_NOSLEEP
         __builtin_amdgcn_s_sleep(1);
-#endif
     }
     st.bad = 1;
     return 0;
@@ -50,18 +45,6 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
 SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
     if (lane == 0)
         __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// SQOA colour op for a pixel whose alpha equals its predecessor's (va == 0): LUMA (2 bytes) or RGB (4 bytes),
-// seqoia.h:606-634 with needs_alpha == 0.  The common case of opaque images, ~17 VALU.
-SQOA_DEV void literal_rgb_only(uint32_t px, uint32_t pv, uint32_t& lo, uint32_t& n) {
-    const int tg = (int)((px >> 8) & 255u) - (int)((pv >> 8) & 255u);
-    const int tr = (int)(px & 255u) - (int)(pv & 255u);
-    const int tb = (int)((px >> 16) & 255u) - (int)((pv >> 16) & 255u);
-    const uint32_t a1 = (uint32_t)((int8_t)(tr - tg) + 8), a2 = (uint32_t)((int8_t)(tb - tg) + 8), a3 = (uint32_t)((int8_t)tg + 32);
-    const bool luma = ((a1 << 2) | (a2 << 2) | a3) < 64u;  // a1 < 16 && a2 < 16 && a3 < 64
-    lo = luma ? (0x80u | a3 | a1 << 12 | a2 << 8) : (px << 8 | 0xfeu);
-    n = luma ? 2u : 4u;
 }
 
 // Op bytes of a pixel that differs from its predecessor (reference seqoia.h:584-635),
@@ -114,30 +97,6 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     const uint32_t t0 = a + 16u * nb;
     if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
     for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
-}
-
-
-// ---- branch-free main pass for SQOA colour sub-tiles that lie fully inside the image ----------------
-// One call classifies a step: op bytes of every pixel (literal, 0xfd, or a short run flush); run flushes
-// longer than one byte (remainder >= 62, rare) only reserve their space here and are written by the caller.
-struct StepOut { uint32_t lo, hi, n, big; };
-
-SQOA_DEV StepOut classify_step(uint32_t px, uint32_t prev, uint32_t nxt, unsigned long long e, uint32_t crun,
-                               bool end_lane, int lane, unsigned long long le_mask) {
-    StepOut o;
-    literal_op<false>(px, prev, false, o.lo, o.hi, o.n);
-    const bool iseq = px == prev;
-    const unsigned long long below = ~e & le_mask;
-    const uint32_t k = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) : crun + lane + 1u;
-    const uint32_t r = k & 511u;                                  // seqoia.h:546-549
-    const bool fd = iseq && (r == 0u || end_lane);                // 512th pixel of a run, or trailing run (seqoia.h:640-642)
-    const bool fl = iseq && !fd && nxt != px;                     // last pixel of a run: owns the flush (seqoia.h:554-561)
-    const uint32_t q = ((r - 1u) * 1075u) >> 16;                  // (r-1)/61 for r <= 511
-    const uint32_t last = fd ? 0xfdu : 0xc0u | (r - 1u - 61u * q);
-    const bool one = fd || (fl && q == 0u);
-    if (iseq) { o.lo = one ? last : 0u; o.hi = 0u; o.n = fd ? 1u : fl ? q + 1u : 0u; }
-    o.big = (fl && q != 0u) ? (q << 8 | last) : 0u;
-    return o;
 }
 
 template <int W, bool QOI>
@@ -196,18 +155,10 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 #pragma unroll
         for (int s = 0; s < ENC_S; ++s) {
             const uint32_t idx = base + s * 64 + lane;
-#ifdef SQOA_DBG_NOLOAD
-            px[s] = idx * 0x9E3779B9u;
-#else
             px[s] = idx < N ? load_px(src, idx, ch) : 0u;
-#endif
         }
-#ifdef SQOA_DBG_NOLOAD
-        pb = base * 0x9E3779B9u; pa = base + 77u;
-#else
         pb = base ? load_px(src, base - 1, ch) : kPxInit;
         pa = base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u;
-#endif
     };
 
     uint32_t j = w;
@@ -226,23 +177,17 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
         // ---- pre-pass: equality masks, local run aggregate -----------------------------
         unsigned long long E[ENC_S];
-        unsigned long long alpha_moves = 0;  // some pixel's alpha differs from its predecessor's
-        const bool full = base + ENC_SUB <= N;
         {
             uint32_t carry = pb;
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) {
                 const uint32_t px = cur[s];
-                const uint32_t x = px ^ shift_up1(px, carry);
+                const uint32_t prev = shift_up1(px, carry);
                 carry = bcast_lane(px, 63);
                 const uint32_t idx = base + s * 64 + lane;
-                E[s] = full ? __ballot(x == 0u) : __ballot(x == 0u && idx < N);
-                alpha_moves |= __ballot(x > 0x00ffffffu);
+                E[s] = __ballot(px == prev && idx < N);
             }
         }
-        // fast paths: SQOA, colour, every lane of the sub-tile inside the image
-        const bool fast = !QOI && !mono && full;
-        const bool flat_alpha = alpha_moves == 0ull;
         uint32_t trail = 0;
         bool all_eq = true;
 #pragma unroll
@@ -296,53 +241,8 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         }
 
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
-        uint32_t sbase = 0;    // bytes staged so far
-        if (!QOI && fast) {
-            // software-pipelined and branch-free: step s+1 is classified while step s is scanned and
-            // staged, so the DPP chains of one overlap the integer code of the other
-            uint32_t cr[ENC_S + 1];
-            cr[0] = c_in;
-#pragma unroll
-            for (int s = 0; s < ENC_S; ++s) cr[s + 1] = E[s] == ~0ull ? cr[s] + 64u : (uint32_t)__builtin_clzll(~E[s]);
-            auto classify = [&](int s) {
-                const uint32_t px = cur[s];
-                const uint32_t prev = shift_up1(px, s ? bcast_lane(cur[s ? s - 1 : 0], 63) : pb);
-                const uint32_t nxt = shift_down1(px, s + 1 < ENC_S ? bcast_lane(cur[(s + 1) % ENC_S], 0) : (has_after ? pa : ~px));
-                const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
-                return classify_step(px, prev, nxt, E[s], cr[s], end_lane, lane, le_mask);
-            };
-            StepOut nx = classify(0);
-#pragma unroll
-            for (int s = 0; s < ENC_S; ++s) {
-                const StepOut c = nx;
-                if (s + 1 < ENC_S) nx = classify(s + 1);
-                const uint32_t incl = wave_incl_scan(c.n);
-                const uint32_t o = sbase + incl - c.n;
-                sbase += bcast_lane(incl, 63);
-                const uint32_t sh = (o & 3u) * 8u;
-                const unsigned long long v = ((unsigned long long)c.hi << 32 | c.lo) << sh;
-                uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
-#ifdef SQOA_DBG_NOEMIT
-                asm volatile("" ::"v"(v), "v"(p));
-#else
-                if (c.n) {
-                    __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-#endif
-                if (__ballot(c.big != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
-                    if (c.big) {
-                        const uint32_t q = c.big >> 8, last = c.big & 255u;
-                        for (uint32_t t = 0; t <= q; ++t) {
-                            const uint32_t ob = o + t;
-                            __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        }
-                    }
-                }
-            }
-        } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
+        uint32_t sbase = 0;    // bytes staged so far
         uint32_t carry = pb;
 #pragma unroll
         for (int s = 0; s < ENC_S; ++s) {
@@ -417,14 +317,11 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
             }
             crun = e == ~0ull ? crun + 64u : (uint32_t)__builtin_clzll(~e);
         }
-        }
 
         // ---- output position from the chain, then drain the staging buffer -------------
         const uint32_t pos = j == 0 ? hdr_len : chain_wait(&s_pos[(j - 1) % W], j, st);
         if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
-#ifndef SQOA_DBG_NOFLUSH
         flush_stage(stage, sbase, dst + pos, lane);
-#endif
         if (last_sub) {  // seqoia.h:644-649
             const uint32_t end = pos + sbase;
             if (lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
@@ -446,10 +343,9 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-#ifndef SQOA_ENC_W
-#define SQOA_ENC_W 4
-#endif
-    constexpr int W = SQOA_ENC_W;
+    // 8 waves per image: the kernel is VALU-issue bound (most of its ops are 8-byte VOP3/SDWA/DPP encodings,
+    // which issue at half the rate of 4-byte VOP2 on gfx950: tools/ubench/valu_rate.hip), more resident waves help
+    constexpr int W = 8;
     if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     return hipGetLastError();
