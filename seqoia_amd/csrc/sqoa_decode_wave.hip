@@ -5,7 +5,8 @@
 // Streams with SQOA_OP_REF, mono streams, QOI streams and 1/2-channel outputs are handed to the
 // exact serial kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
 //
-// Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W):
+// Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W, and
+// inside a chunk every lane owns 8 consecutive stream bytes):
 //   1. parse: every byte gets a transition function over the 7 parser states
 //      {A: op boundary after an op, N: op boundary where an ALPHA suffix is not allowed,
 //       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes, composition is two
@@ -93,11 +94,38 @@ SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int 
     }
 }
 
+// A pixel transform: v8 holds 4 packed channels, `abs` the byte mask of channels that are absolute;
+// the other channels are deltas (mod 256) still to be added to whatever pixel enters.
+struct Xf { uint32_t v, abs; };
+// first `a`, then `b`
+SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{(add8(a.v, b.v) & ~b.abs) | (b.v & b.abs), a.abs | b.abs}; }
+SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return (add8(px, t.v) & ~t.abs) | (t.v & t.abs); }
+
+template <int CTRL, int ROWMASK>
+SQOA_DEV Xf xf_scan_step(Xf T) {
+    Xf P;  // the transform of the lanes below, identity where there is none
+    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, false);
+    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, false);
+    return xf_then(P, T);
+}
+SQOA_DEV Xf wave_xf_scan(Xf T) {
+    T = xf_scan_step<DPP_ROW_SHR + 1, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 2, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 4, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 8, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_BCAST15, 0xa>(T);
+    T = xf_scan_step<DPP_ROW_BCAST31, 0xc>(T);
+    return T;
+}
+
+constexpr int DEC_LB = 8;  // stream bytes owned by one lane (64 lanes x 8 = one 512-byte chunk per step)
+
 template <int W>
 __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
+    __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
@@ -134,6 +162,12 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         s_path = path;
     }
     if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
+    for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // transition function of a live byte (see header comment)
+        const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+        const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
+        const uint32_t fA = (b0 - 0x60u) < 0x20u ? (uint32_t)ST_N : opn;
+        s_ftab[b0] = fA | opn << 8 | 0x02000000u;
+    }
     __syncthreads();
     if (s_path != 1) return;
 
@@ -146,7 +180,6 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
     const uint32_t chunks_len = size - 8;       // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
-    const unsigned long long le_mask = (2ull << lane) - 1ull;
     uint32_t bad = 0;
 
     uint32_t* lds = s_bytes[w];
@@ -173,121 +206,116 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         if (more) load_chunk(c + W, stg);
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
         const uint8_t* cb = reinterpret_cast<const uint8_t*>(lds) + (gs & 3u);
+        const uint8_t* lb = cb + DEC_LB * lane;                // this lane's 8 bytes
         const bool last_chunk = c == nchunks - 1;
+        // how many of my bytes lie inside the chunk area (op starts beyond it do not exist, seqoia.h:726)
+        const uint32_t my0 = gs + DEC_LB * lane;
+        const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)DEC_LB ? (uint32_t)DEC_LB : chunks_len - my0);
 
-        // ---- 1. parser transition functions, scanned per step; chunk total ------------------
-        Fn fex[DEC_S];       // per lane: composition of all earlier bytes of the step (exclusive)
-        Fn ftot[DEC_S];      // per step: composition of the whole step (uniform)
-        Fn G{ID_LO, ID_HI};
+        // ---- 1. parse: each lane composes the transition functions of its 8 bytes, one wave scan ----
+        unsigned long long q0;
+        __builtin_memcpy(&q0, lb, 8);
+        Fn F{ID_LO, ID_HI};
 #pragma unroll
-        for (int s = 0; s < DEC_S; ++s) {
-            const uint32_t i = s * 64 + lane;
-            const uint32_t b0 = cb[i];
-            const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
-            const bool sfx = (b0 - 0x60u) < 0x20u;
-            const bool live = gs + i < chunks_len;
-            const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
-            const uint32_t fA = !live ? (uint32_t)ST_X : sfx ? (uint32_t)ST_N : opn;
-            const uint32_t fN = !live ? (uint32_t)ST_X : opn;
-            Fn F = wave_compose_scan(Fn{fA | fN << 8 | 0x02000000u, 0x07060403u});
-            ftot[s] = Fn{bcast_lane(F.lo, 63), bcast_lane(F.hi, 63)};
-            fex[s] = Fn{shift_up1(F.lo, ID_LO), shift_up1(F.hi, ID_HI)};
-            G = compose(ftot[s], G);
+        for (int k = 0; k < DEC_LB; ++k) {
+            const uint32_t b = (uint32_t)(q0 >> (8 * k)) & 0xffu;
+            const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
+            F = compose(Fn{flo, 0x07060403u}, F);
         }
-        // exit state independent of the entry state?  (states A, N, D1..D4; X cannot enter a chunk
-        // that has a successor)  Then publish before waiting.
-        const uint32_t g0 = bcast_first(G.lo) & 0xffu;
-        const bool g_const = bcast_first(G.lo) == g0 * 0x01010101u && (bcast_first(G.hi) & 0xffffu) == g0 * 0x0101u;
+        const Fn Fi = wave_compose_scan(F);
+        const Fn G{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)};
+        const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
+        // exit state independent of the entry state?  (A, N, D1..D4; X cannot enter a chunk that has a successor)
+        const uint32_t g0 = G.lo & 0xffu;
+        const bool g_const = G.lo == g0 * 0x01010101u && (G.hi & 0xffffu) == g0 * 0x0101u;
         unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
         if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
         if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) break;
-        if (!g_const && !last_chunk) post(my_parse, c + 1, apply(Fn{bcast_first(G.lo), bcast_first(G.hi)}, st_in), lane);
+        if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
 
-        // ---- 2. ops: counts, channel sums, re-basing at absolute ops -------------------------
-        uint32_t meta[DEC_S];   // Prel (20) | cnt (10) << 20 | rgb absolute << 30 | alpha absolute << 31
-        uint32_t vrel[DEC_S];   // pixel value after the op: absolute, or relative to the chunk's entry pixel
-        uint32_t st = st_in, pbase = 0;
-        uint32_t carry_v = 0;           // value entering the step (relative to chunk entry unless absolute)
-        bool carry_rgb_abs = false, carry_a_abs = false;
+        // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
+        const uint32_t lst = apply(Fx, st_in);  // parser state in front of my first byte
+        // first op start: inside an op -> skip its remaining bytes; an ALPHA byte at an op boundary after an
+        // op belongs to that op (whoever owns the op has read it), so it is skipped too
+        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? 8u : 0u);
+        bool sfx_ok = lst != ST_N;  // may the byte at `pos` be an ALPHA suffix of the op before it?
+        uint32_t val[DEC_LB];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
+        uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13 | abs flags << 30
+        Xf T{0u, 0u};
+        uint32_t cl = 0;
         bool ref_seen = false;
 #pragma unroll
-        for (int s = 0; s < DEC_S; ++s) {
-            const uint32_t i = s * 64 + lane;
+        for (int i = 0; i < DEC_LB; ++i) {
             unsigned long long q;
-            __builtin_memcpy(&q, cb + i, 8);  // op byte + up to 4 data bytes + possible ALPHA suffix
-            const uint32_t b0 = (uint32_t)q & 0xffu, b1 = ((uint32_t)q >> 8) & 0xffu;
-            const uint32_t lst = apply(fex[s], st);                 // parser state in front of this byte
-            const bool sfx0 = (b0 - 0x60u) < 0x20u;
-            // op starts: only inside the chunk area (seqoia.h:726), never in states D* / X
-            const bool isop = gs + i < chunks_len && (lst == ST_N || (lst == ST_A && !sfx0));
-            if (__ballot(isop && b0 < 0x60u) != 0ull) { ref_seen = true; break; }  // SQOA_OP_REF: serial path
+            __builtin_memcpy(&q, lb + (pos < 8u ? pos : 8u), 8);  // op byte, <= 4 data bytes, possible ALPHA suffix
+            uint32_t b0 = (uint32_t)q & 0xffu;
+            if (sfx_ok && (b0 - 0x60u) < 0x20u) { pos += 1u; q >>= 8; b0 = (uint32_t)q & 0xffu; }  // only possible for i == 0
+            const bool act = pos < nlive;
+            if (__ballot(act) == 0ull) {
+#pragma unroll
+                for (int r = i; r < DEC_LB; ++r) { val[r] = 0; meta[r] = 0; }
+                break;
+            }
+            if (__ballot(act && b0 < 0x60u) != 0ull) { ref_seen = true; break; }  // SQOA_OP_REF: serial path
+            const uint32_t b1 = ((uint32_t)q >> 8) & 0xffu;
             const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
             const uint32_t sb = (uint32_t)(q >> (8u * len)) & 0xffu;  // byte after the op (seqoia.h:777-783)
-            const uint32_t da = (sb - 0x60u) < 0x20u ? ((sb & 31u) - 16u) & 0xffu : 0u;
-            const bool rgbset = isop && b0 >= 0xfeu, aset = isop && b0 == 0xffu;
-            const bool luma = (b0 & 0xc0u) == 0x80u;
-            uint32_t cnt = 0, X = 0, Y = 0, base = 0;
-            if (isop) {
-                cnt = 1;
-                if (b0 >= 0xfeu) {
-                    base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;
-                    Y = aset ? 0u : da << 16;
-                } else if (luma) {  // seqoia.h:761-769
-                    const uint32_t vg = (b0 & 0x3fu) - 32u;
-                    X = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 16;
-                    Y = ((vg - 8u + (b1 & 15u)) & 0xffu) | da << 16;
-                } else {            // RUN / BIGRUN, or a byte 0x60..0x7f in op position (seqoia.h:770-775)
-                    cnt = b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u;
-                    Y = da << 16;
-                }
+            const bool has_sfx = (sb - 0x60u) < 0x20u;
+            const uint32_t da = has_sfx ? ((sb & 31u) - 16u) & 0xffu : 0u;
+            uint32_t cnt = 1, d8 = da << 24, setm = 0, base = 0;
+            if (b0 >= 0xfeu) {
+                setm = b0 == 0xffu ? 0xffffffffu : 0x00ffffffu;
+                base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;
+                if (b0 == 0xffu) d8 = 0;
+            } else if ((b0 & 0xc0u) == 0x80u) {  // LUMA, seqoia.h:761-769
+                const uint32_t vg = (b0 & 0x3fu) - 32u;
+                d8 |= ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
+            } else {                            // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775)
+                cnt = b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u;
             }
-            // prefix sums: pixels, and channel deltas in 16-bit fields (64 * 255 < 65536, no carries)
-            const uint32_t cinc = wave_incl_scan(cnt);
-            const uint32_t SX = wave_incl_scan(X), SY = wave_incl_scan(Y);
-            const uint32_t S8 = __builtin_amdgcn_perm(SY, SX, 0x06040200u);  // r g b a sums, mod 256
-            const uint32_t K8 = sub8(base, S8);                                // absolute op: value minus the sums up to it
-            const unsigned long long mrgb = __ballot(rgbset) & le_mask, ma = __ballot(aset) & le_mask;
-            const int jrgb = mrgb ? 63 - __builtin_clzll(mrgb) : lane, ja = ma ? 63 - __builtin_clzll(ma) : lane;
-            const uint32_t krgb = (uint32_t)__builtin_amdgcn_ds_bpermute(jrgb << 2, (int)K8);
-            const uint32_t ka = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)K8);
-            const uint32_t kb = ((mrgb ? krgb : carry_v) & 0x00ffffffu) | ((ma ? ka : carry_v) & 0xff000000u);
-            const uint32_t v = add8(kb, S8);
-            const bool rgb_abs = mrgb != 0ull || carry_rgb_abs, a_abs = ma != 0ull || carry_a_abs;
-            vrel[s] = v;
-            meta[s] = (pbase + cinc - cnt) | cnt << 20 | (rgb_abs ? 1u << 30 : 0u) | (a_abs ? 1u << 31 : 0u);
-            // carry to the next step
-            const uint32_t tot = bcast_lane(cinc, 63);
-            pbase += tot;  // <= 512 ops * 512 pixels = 2^18 per chunk: fits the 20-bit field
-            carry_v = bcast_lane(v, 63);
-            carry_rgb_abs = carry_rgb_abs || __ballot(rgbset) != 0ull;
-            carry_a_abs = carry_a_abs || __ballot(aset) != 0ull;
-            st = apply(ftot[s], st);
+            if (act) {
+                T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm});
+                val[i] = T.v;
+                meta[i] = cl | cnt << 13 | (T.abs & 1u) << 30 | (T.abs >> 31) << 31;
+                cl += cnt;
+                pos += len + (has_sfx ? 1u : 0u);
+            } else { val[i] = 0; meta[i] = 0; }
+            sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
         if (ref_seen) {
             if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
             break;
         }
 
-        // ---- 3. entry position / pixel from the chain, publish exits, store ------------------
+        // ---- 3. wave scans: pixel positions and pixel transforms of the lanes below ------------
+        const uint32_t cinc = wave_incl_scan(cl);
+        const uint32_t ctot = bcast_lane(cinc, 63);
+        const Xf Ti = wave_xf_scan(T);
+        const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
+        const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
+
+        // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
         uint32_t pos_in = 0, px_in = kPxInit;
         if (c > 0) {
             if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) break;
             if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) break;
         }
-        const uint32_t exit_v = ((carry_rgb_abs ? carry_v : add8(px_in, carry_v)) & 0x00ffffffu) |
-                                ((carry_a_abs ? carry_v : add8(px_in, carry_v)) & 0xff000000u);
-        const uint32_t pos_out = pos_in + pbase > N ? N : pos_in + pbase;
+        const uint32_t exit_v = xf_apply(Tg, px_in);
+        const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
         if (!last_chunk) { post(&s_px[w], c + 1, exit_v, lane); post(&s_pos[w], c + 1, pos_out, lane); }
 
         if (pos_in < N) {
+            const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
+            const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
 #pragma unroll
-            for (int s = 0; s < DEC_S; ++s) {
-                const uint32_t m = meta[s];
-                const uint32_t cnt = (m >> 20) & 0x3ffu;
-                const uint32_t P = pos_in + (m & 0xfffffu);
-                const uint32_t rel = add8(px_in, vrel[s]);
-                const uint32_t v = (((m >> 30) & 1u ? vrel[s] : rel) & 0x00ffffffu) | ((m >> 31 ? vrel[s] : rel) & 0xff000000u);
+            for (int i = 0; i < DEC_LB; ++i) {
+                const uint32_t m = meta[i];
+                const uint32_t cnt = (m >> 13) & 0x3ffu;
+                if (__ballot(cnt != 0u) == 0ull) break;
+                const uint32_t P = lane_p + (m & 0x1fffu);
+                const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
+                const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
                 if (cnt == 1u && P < N) {
                     if (oc == 4) ((gptr32)out)[P] = v;
                     else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
@@ -320,7 +348,10 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
                                               sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    constexpr int W = 4;
+#ifndef SQOA_DEC_W
+#define SQOA_DEC_W 8
+#endif
+    constexpr int W = SQOA_DEC_W;
     hipLaunchKernelGGL((sqoa::decode_wave_kernel<W>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     return hipGetLastError();
 }
