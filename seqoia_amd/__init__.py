@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     SQOA_LINEAR,
     SQOA_SRGB,
     DecodePlan,
+    EncodeList,
     EncodePlan,
     Plan,
     decode,

@@ -153,6 +153,36 @@ class EncodePlan(Plan):
         return [bytes(self.out[i, : int(res["len"][i])].cpu().numpy()) for i in idx]
 
 
+class EncodeList(Plan):
+    """Encode images of different shapes in one plan (BASELINE config 5 shape: a suite of mixed sizes).
+
+    ``images``: list of (torch uint8 CUDA tensor holding h*w*stride bytes, Desc).  All output
+    slots live in one buffer ``self.out`` at ``self.offsets``; ``streams()`` copies them out.
+    """
+
+    def __init__(self, images):
+        import torch
+
+        dev = images[0][0].device
+        self.images = images
+        self.slots = [encode_bound(d) for _, d in images]
+        self.offsets = [0]
+        for sl in self.slots:
+            self.offsets.append(self.offsets[-1] + sl)
+        self.out = torch.empty((max(self.offsets[-1], 1),), dtype=torch.uint8, device=dev)
+        base = self.out.data_ptr()
+        jobs = []
+        for (t, d), off, sl in zip(images, self.offsets, self.slots):
+            assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+            jobs.append(Job(t.data_ptr(), base + off, 0, min(sl, 0xFFFFFFFF), d, 0))
+        super().__init__(ENCODE, jobs, _device_index(images[0][0]))
+
+    def streams(self):
+        res = self.results()
+        return [None if res["status"][i] else bytes(self.out[o : o + int(res["len"][i])].cpu().numpy())
+                for i, o in enumerate(self.offsets[:-1])]
+
+
 class DecodePlan(Plan):
     """Decode n streams held in device memory.
 

@@ -1,0 +1,81 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol the headers declare,
+keeps the reference's struct layout, and refuses bad arguments exactly where the reference does
+before touching the device (seqoia.h:465-480, :662-668)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+import seqoia_amd
+from seqoia_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for hdr in ("seqoia.h", "sqoa_hip.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sqoa_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = seqoia_amd.load()
+    names = declared_functions()
+    assert {"sqoa_encode", "sqoa_decode", "sqoa_read", "sqoa_write", "sqoa_hip_plan_create", "sqoa_hip_plan_launch"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert names == set(_lib.SYMBOLS), names ^ set(_lib.SYMBOLS)
+
+
+def test_struct_layouts_match_the_reference_abi():
+    # sqoa_desc: {unsigned, unsigned, uchar, uchar, uchar}, sizeof 12 (seqoia.h:318-324)
+    assert C.sizeof(_lib.Desc) == 12
+    assert [(_lib.Desc.width.offset), (_lib.Desc.height.offset), _lib.Desc.channels.offset, _lib.Desc.colorspace.offset,
+            _lib.Desc.qoi_compat.offset] == [0, 4, 8, 9, 10]
+    assert C.sizeof(_lib.Job) == 40 and C.sizeof(_lib.Result) == 20
+
+
+def test_header_compiles_as_c_and_cpp_and_links(tmp_path):
+    """A reference-style caller: #define SQOA_IMPLEMENTATION + #include "seqoia.h" (sqoabench.c:31-32)."""
+    src = tmp_path / "caller.c"
+    src.write_text(
+        '#define SQOA_IMPLEMENTATION\n#include "seqoia.h"\n#include <stdlib.h>\n'
+        "int main(void){ int n=0; unsigned char px[4]={1,2,3,4};\n"
+        " void *p = sqoa_encode(px, &(sqoa_desc){.width=0,.height=1,.channels=4,.colorspace=SQOA_SRGB,.qoi_compat=0}, &n);\n"
+        " sqoa_desc d; void *q = sqoa_decode(px, 4, &d, 4);\n"
+        " return (p==NULL && q==NULL && sizeof(sqoa_desc)==12) ? 0 : 1; }\n"
+    )
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "caller"
+    subprocess.run(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                    "-lsqoa_mi355x", f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    cpp = tmp_path / "caller.cpp"
+    cpp.write_text('#include "seqoia.h"\n#include "sqoa_hip.h"\nint main(){ sqoa_desc d{}; return sqoa_hip_encode_bound(&d) == 0 ? 0 : 1; }\n')
+    subprocess.run(["g++", "-I", os.path.join(ROOT, "include"), str(cpp), "-o", str(exe), "-L", libdir, "-lsqoa_mi355x",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_argument_checks_need_no_device():
+    px = np.zeros(64, np.uint8)
+    D = seqoia_amd.Desc
+    for d in (D(0, 4, 4, 0, 0), D(4, 0, 4, 0, 0), D(4, 4, 0, 0, 0), D(4, 4, 7, 0, 0), D(4, 4, 4, 2, 0), D(20000, 20000, 4, 0, 0),
+              D(4, 4, 1, 0, 1), D(4, 4, 2, 0, 1)):
+        assert seqoia_amd.encode(px, d) is None
+    assert seqoia_amd.decode(b"\0" * 21, 4)[0] is None          # shorter than header + padding
+    assert seqoia_amd.decode(b"Sqoa" + b"\0" * 30, 5)[0] is None  # channels > 4
+    assert seqoia_amd.decode(b"Sqob" + b"\0" * 30, 4)[0] is None  # bad magic: rejected on the host
+
+
+def test_encode_bound_matches_reference_formula():
+    # w*h*(ch+1)+14+8 (seqoia.h:487-489) + 1 start byte (seqoia.h:513), rounded up to 256
+    for w, h, c, ch in ((1, 1, 4, 4), (1024, 1024, 4, 4), (64, 64, 3, 3), (10, 10, 5, 3), (10, 10, 6, 4), (7, 3, 1, 1), (7, 3, 2, 2)):
+        raw = w * h * (ch + 1) + 14 + 8 + 1
+        assert seqoia_amd.encode_bound(seqoia_amd.Desc(w, h, c, 0, 0)) == (raw + 255) // 256 * 256
+    assert seqoia_amd.encode_bound(seqoia_amd.Desc(0, 1, 4, 0, 0)) == 0

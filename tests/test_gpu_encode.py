@@ -147,3 +147,37 @@ def test_headline_batch_properties(sq, orc, synth_digests):
     for k in (0, 17, 63):
         assert plan.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, 0)
     plan.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_mixed_size_suite_in_one_plan(sq, orc, mode):
+    """BASELINE config 5 shape at reduced count: a qoi-suite-like mix of sizes and channel counts
+    (SURVEY.md Appendix C size table) in ONE plan, including mono / BGR layouts and a refused job."""
+    import torch
+
+    o = orc.best()
+    shapes = [(64, 64, 4, "icon"), (512, 512, 4, "icon"), (190, 190, 4, "mixed"), (367, 368, 3, "mixed"), (768, 512, 3, "photo"),
+              (553, 553, 4, "mixed"), (800, 800, 4, "mixed"), (1200, 1200, 3, "photo"), (1024, 1024, 3, "photo"), (1, 7, 4, "mixed"),
+              (640, 480, 5, "mixed"), (320, 200, 6, "mixed"), (300, 300, 1, "photo"), (300, 300, 2, "mixed")]
+    images, raws = [], []
+    for k, (w, h, c, cls) in enumerate(shapes):
+        stride = sq.stride_channels(c)
+        if stride >= 3:
+            raw = orc.synth(w, h, stride, cls, 9, k)
+        else:  # mono layouts: take channels of a synthetic RGBA image
+            raw = orc.synth(w, h, 4, cls, 9, k).reshape(-1, 4)[:, [1, 3][:stride]].reshape(-1).copy()
+        raws.append(raw)
+        images.append((torch.from_numpy(raw).cuda(), sq.Desc(w, h, c, 0, mode)))
+    images.append((torch.zeros(16, dtype=torch.uint8, device="cuda"), sq.Desc(0, 4, 4, 0, mode)))  # invalid: width 0
+    plan = sq.EncodeList(images)
+    plan.launch()
+    res = plan.results()
+    got = plan.streams()
+    for k, (w, h, c, cls) in enumerate(shapes):
+        want = o.encode(raws[k], w, h, c, mode)
+        if want is None:  # mono + qoi_compat (seqoia.h:477-480)
+            assert res["status"][k] == 1 and got[k] is None, shapes[k]
+        else:
+            assert res["status"][k] == 0 and got[k] == want, shapes[k]
+    assert res["status"][len(shapes)] == 1 and res["len"][len(shapes)] == 0
+    plan.close()

@@ -1,0 +1,79 @@
+"""Multi-rank sharding logic on CPU (gloo, world_size 2): the N>1 path of bench.py and of any
+batch front-end.  No GPU and no codec involved: images are represented by their pixel counts and the
+"encode" of a rank is the oracle, so this also checks that a sharded job reproduces the unsharded
+result image for image."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from seqoia_amd import shard
+
+
+def test_contiguous_blocks_cover_everything():
+    for n in (0, 1, 7, 1024, 65536):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += list(shard.contiguous(n, world, r))
+            assert seen == list(range(n))
+            sizes = [len(shard.contiguous(n, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_lpt_balances_suite_shaped_sizes():
+    # SURVEY.md Appendix C suite-shaped size table (pixels per image), replicated
+    rng = np.random.default_rng(0)
+    sizes = [64 * 64] * 226 + [512 * 512] * 214 + [36000] * 1010 + [640000] * 619 + [1800000] * 187 + [8100000] * 14
+    rng.shuffle(sizes)
+    parts = shard.lpt(sizes, 8)
+    assert sorted(i for p in parts for i in p) == list(range(len(sizes)))
+    loads = [sum(sizes[i] for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.02  # within 2 % of perfect balance
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+
+    shapes = [(64, 64, 3), (100, 37, 4), (33, 5, 4), (128, 16, 3), (17, 17, 4), (256, 8, 4), (5, 5, 3)]
+    mine = shard.lpt([w * h for w, h, _ in shapes], world)[rank]
+    lens = []
+    for i in mine:
+        w, h, ch = shapes[i]
+        lens.append(len(po.restatement().encode(po.synth(w, h, ch, "mixed", 3, i), w, h, ch, 0)))
+    allv = shard.gather_lengths(mine, lens, len(shapes))
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the timing reduction bench.py does
+    if rank == 0:
+        q.put((allv, float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_reproduce_single_rank():
+    from oracle import pyoracle as po
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allv, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [(64, 64, 3), (100, 37, 4), (33, 5, 4), (128, 16, 3), (17, 17, 4), (256, 8, 4), (5, 5, 3)]
+    want = [len(po.restatement().encode(po.synth(w, h, ch, "mixed", 3, i), w, h, ch, 0)) for i, (w, h, ch) in enumerate(shapes)]
+    assert allv == want
+    assert tmax == 2.0
