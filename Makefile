@@ -14,7 +14,7 @@ CFLAGS_HOST := -std=gnu99 -O2 -fPIC -Wall -Wextra
 KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_decode_wave.hip $(CSRC)/sqoa_runtime.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNELS)) $(BUILD)/sqoa_host.o
 
-all: lib oracle
+all: lib oracle tools
 
 lib: $(OUT)/libsqoa_mi355x.so
 
@@ -33,7 +33,13 @@ $(OUT)/libsqoa_mi355x.so: $(OBJS)
 oracle:
 	$(MAKE) -s -C oracle
 
-clean:
-	rm -rf $(BUILD) $(OUT)/*.so
+TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x
+tools: lib $(TOOLS)
+tools/bin/%: tools/%.c include/seqoia.h include/sqoa_hip.h
+	@mkdir -p tools/bin
+	$(CC) -std=gnu99 -O2 -Wall -Iinclude $< -o $@ -L$(OUT) -lsqoa_mi355x -Wl,-rpath,'$$ORIGIN/../../$(OUT)'
 
-.PHONY: all lib oracle clean
+clean:
+	rm -rf $(BUILD) $(OUT)/*.so tools/bin
+
+.PHONY: all lib oracle tools clean

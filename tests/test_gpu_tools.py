@@ -1,0 +1,51 @@
+"""The C harnesses (plain-C callers of the drop-in header + library): sqoaconv-style file round trip
+(sqoa_read / sqoa_write, seqoia.h:336/:350, call shapes of sqoaconv.c:65/:84-90) and the sqoabench-style
+benchmark with its round-trip verify (sqoabench.c:448-455)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tools", "bin")
+
+
+def pam(path, px, w, h, ch):
+    t = {1: "GRAYSCALE", 2: "GRAYSCALE_ALPHA", 3: "RGB", 4: "RGB_ALPHA"}[ch]
+    with open(path, "wb") as f:
+        f.write(f"P7\nWIDTH {w}\nHEIGHT {h}\nDEPTH {ch}\nMAXVAL 255\nTUPLTYPE {t}\nENDHDR\n".encode())
+        f.write(px.tobytes())
+
+
+def test_sqoaconv_file_roundtrip(tmp_path):
+    from oracle import pyoracle as po
+
+    if not os.path.exists(os.path.join(BIN, "sqoaconv_mi355x")):
+        subprocess.run(["make", "-s", "-C", ROOT, "tools"], check=True)
+    conv = os.path.join(BIN, "sqoaconv_mi355x")
+    for ch, cls in ((4, "mixed"), (3, "icon"), (1, "photo")):
+        w, h = 200, 120
+        px = po.synth(w, h, 4, cls, 2, 0).reshape(-1, 4)[:, :ch].copy() if ch != 1 else po.synth(w, h, 4, cls, 2, 0).reshape(-1, 4)[:, 1:2].copy()
+        src = tmp_path / f"in{ch}.pam"
+        pam(src, px, w, h, ch)
+        sq, qoi, back = tmp_path / f"a{ch}.sqoa", tmp_path / f"a{ch}.qoi", tmp_path / f"b{ch}.pam"
+        assert subprocess.run([conv, str(src), str(sq)]).returncode == 0
+        assert sq.read_bytes() == po.best().encode(px.reshape(-1), w, h, ch, 0)       # byte-identical .sqoa file
+        if ch >= 3:
+            assert subprocess.run([conv, str(sq), str(qoi)]).returncode == 0           # .sqoa -> .qoi
+            assert qoi.read_bytes() == po.best().encode(px.reshape(-1), w, h, ch, 1)
+            assert subprocess.run([conv, str(qoi), str(back)]).returncode == 0          # .qoi -> raw
+        else:
+            assert subprocess.run([conv, str(sq), str(qoi)]).returncode != 0           # mono cannot be QOI (seqoia.h:477-480)
+            assert subprocess.run([conv, str(sq), str(back)]).returncode == 0
+        assert back.read_bytes().split(b"ENDHDR\n", 1)[1] == px.tobytes()
+    assert subprocess.run([conv, str(tmp_path / "missing.sqoa"), str(tmp_path / "x.pam")]).returncode != 0
+
+
+def test_sqoabench_synth_runs_and_verifies():
+    bench = os.path.join(BIN, "sqoabench_mi355x")
+    r = subprocess.run([bench, "2", "--synth", "mixed", "256", "256", "4", "16"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "sqoa-batch:" in r.stdout and "decode mpps" in r.stdout
