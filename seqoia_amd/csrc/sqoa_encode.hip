@@ -99,6 +99,145 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
 }
 
+
+// ---- SWAR main pass: four 64-pixel rows at a time, one byte lane per row -------------------------------
+// gfx950 issues 4-byte VOP2 encodings at twice the rate of the 8-byte VOP3 / SDWA / DPP ones
+// (tools/ubench/valu_rate.hip), and the per-pixel op decision (seqoia.h:584-635) is all 8-bit arithmetic.
+// So the decision is made for the same lane of FOUR rows at once: the four pixels are transposed into one
+// dword per channel (v_perm_b32), channel deltas, the vg_r / vg_b terms, the range tests and the LUMA
+// byte fields are computed bytewise inside dwords with plain and/or/add/sub/xor, and only the final
+// assembly of each pixel's bytes and its LDS store is done per row.
+template <uint32_t V>
+SQOA_DEV uint32_t sconst() {  // a constant the compiler must keep in an SGPR (usable as VOP2 src0, no literal dword)
+    uint32_t r;
+    asm("s_mov_b32 %0, %1" : "=s"(r) : "n"(V));
+    return r;
+}
+
+struct RunOut { uint32_t lo, n, big; };
+// Bytes owned by a pixel that repeats its predecessor (seqoia.h:544-561, :640-642): 0xfd on every 512th pixel
+// of a run and on a trailing run, the flush (owned by the run's last pixel) otherwise; flushes longer than one
+// byte only reserve their space (big = q << 8 | last byte).
+SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long enext, bool end_lane, int lane,
+                        unsigned long long le_mask) {
+    const bool iseq = (e >> lane) & 1ull;
+    const unsigned long long below = ~e & le_mask;
+    const uint32_t k = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) : crun + lane + 1u;
+    const uint32_t r = k & 511u;
+    const bool fd = iseq && (r == 0u || end_lane);
+    const bool fl = iseq && !fd && !((enext >> lane) & 1ull);
+    const uint32_t q = ((r - 1u) * 1075u) >> 16;  // (r-1)/61 for r <= 511
+    const uint32_t last = fd ? 0xfdu : 0xc0u | (r - 1u - 61u * q);
+    RunOut o;
+    o.lo = (fd || (fl && q == 0u)) ? last : 0u;
+    o.n = fd ? 1u : fl ? q + 1u : 0u;
+    o.big = (fl && q != 0u) ? (q << 8 | last) : 0u;
+    return o;
+}
+
+SQOA_DEV uint32_t swar_main_pass(const uint32_t (&cur)[ENC_S], const unsigned long long (&E)[ENC_S], uint32_t c_in, uint32_t pb,
+                                 uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask) {
+    const uint32_t H = sconst<0x80808080u>(), L = sconst<0x7f7f7f7fu>();
+    const uint32_t C08 = sconst<0x08080808u>(), C20 = sconst<0x20202020u>(), C10 = sconst<0x10101010u>();
+    const uint32_t MF0 = sconst<0xf0f0f0f0u>(), MC0 = sconst<0xc0c0c0c0u>(), ME0 = sconst<0xe0e0e0e0u>(), M0F = sconst<0x0f0f0f0fu>();
+    const uint32_t C60 = sconst<0x60606060u>(), CFE = sconst<0xfefefefeu>(), ONES = sconst<0x01010101u>();
+    auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
+    auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
+
+    uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
+    cr[0] = c_in;
+#pragma unroll
+    for (int s = 0; s < ENC_S; ++s) cr[s + 1] = E[s] == ~0ull ? cr[s] + 64u : (uint32_t)__builtin_clzll(~E[s]);
+
+    uint32_t sbase = 0;
+    uint32_t c0 = pb;  // pixel in front of the group's first row
+#pragma unroll
+    for (int g = 0; g < ENC_S / 4; ++g) {
+        const uint32_t P0 = cur[4 * g], P1 = cur[4 * g + 1], P2 = cur[4 * g + 2], P3 = cur[4 * g + 3];
+        // one dword per channel, byte i = row i
+        const uint32_t a01 = __builtin_amdgcn_perm(P1, P0, 0x05010400u), b01 = __builtin_amdgcn_perm(P1, P0, 0x07030602u);
+        const uint32_t a23 = __builtin_amdgcn_perm(P3, P2, 0x05010400u), b23 = __builtin_amdgcn_perm(P3, P2, 0x07030602u);
+        const uint32_t R = __builtin_amdgcn_perm(a23, a01, 0x05040100u), G = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+        const uint32_t B = __builtin_amdgcn_perm(b23, b01, 0x05040100u), A = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+        // the same for the predecessor pixels: lane-1, and for lane 0 the last pixel of the row above
+        const uint32_t Rp = shift_up1(R, bcast_lane(R, 63) << 8 | (c0 & 255u));
+        const uint32_t Gp = shift_up1(G, bcast_lane(G, 63) << 8 | ((c0 >> 8) & 255u));
+        const uint32_t Bp = shift_up1(B, bcast_lane(B, 63) << 8 | ((c0 >> 16) & 255u));
+        const uint32_t Ap = shift_up1(A, bcast_lane(A, 63) << 8 | (c0 >> 24));
+        c0 = bcast_lane(P3, 63);
+        // channel deltas mod 256 (seqoia.h:585-588), vg_r / vg_b (seqoia.h:589-590) with the range-test bias folded in
+        const uint32_t DR = sub8(R, Rp), DG = sub8(G, Gp), DB = sub8(B, Bp), DA = sub8(A, Ap);
+        const uint32_t DGm = ((DG | H) - C08) ^ ((DG & H) ^ H);                 // vg - 8
+        const uint32_t XR = sub8(DR, DGm), XB = sub8(DB, DGm);                  // vg_r + 8, vg_b + 8
+        const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
+        const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
+        const uint32_t b0 = nz(DR | DG | DB | DA) >> 7;                         // 1 = differs from its predecessor
+        const uint32_t b1 = nz(bad) >> 7, b2 = nz(DA) >> 7;                     // 1 = needs RGB/RGBA; 1 = alpha moved
+        const uint32_t na_mask = (b2 << 8) - b2, raw_mask = (b1 << 8) - b1;     // 0xff where set
+        const uint32_t L0 = XG | H;                                             // LUMA byte 0 (seqoia.h:612)
+        const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);                     // LUMA byte 1 (seqoia.h:614)
+        const uint32_t L2 = (XA | C60) & na_mask;                               // ALPHA suffix (seqoia.h:617)
+        const uint32_t TG = CFE | b2;                                           // RGB / RGBA tag (seqoia.h:622)
+        const uint32_t AH = A & na_mask & raw_mask;                             // 5th byte of RGBA
+        uint32_t Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);                      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+
+        // pixels that repeat their predecessor: run bookkeeping per row, skipped for rows without any
+        uint32_t rlo[4] = {0, 0, 0, 0}, rbig[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = 4 * g + i;
+            const unsigned long long e = E[s];
+            if (e != 0ull) {
+                const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
+                const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
+                const RunOut ro = run_row(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
+                rlo[i] = ro.lo;
+                rbig[i] = ro.big;
+                Nn += ro.n << (8 * i);
+            }
+        }
+
+        // byte offsets: two DPP prefix sums over 16-bit fields cover the four rows
+        const uint32_t i01 = wave_incl_scan(__builtin_amdgcn_perm(Nn, Nn, 0x0c010c00u));
+        const uint32_t i23 = wave_incl_scan(__builtin_amdgcn_perm(Nn, Nn, 0x0c030c02u));
+        const uint32_t t01 = bcast_lane(i01, 63), t23 = bcast_lane(i23, 63);
+        const uint32_t rowbase[4] = {sbase, sbase + (t01 & 0xffffu), sbase + (t01 & 0xffffu) + (t01 >> 16),
+                                     sbase + (t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu)};
+        sbase = rowbase[3] + (t23 >> 16);
+        const uint32_t Pn[4] = {P0, P1, P2, P3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t n = (Nn >> (8 * i)) & 255u;
+            const uint32_t incl = ((i < 2 ? i01 : i23) >> (16 * (i & 1))) & 0xffffu;
+            const uint32_t o = rowbase[i] + incl - n;
+            const uint32_t lw = __builtin_amdgcn_perm(L1, L0, 0x0c0c0400u + i * 0x0101u);           // L0.i, L1.i, 0, 0
+            const uint32_t lw3 = __builtin_amdgcn_perm(L2, lw, 0x0c040100u + i * 0x10000u);         // + L2.i
+            const uint32_t rw = __builtin_amdgcn_perm(Pn[i], TG, 0x06050400u + i);                  // tag, r, g, b
+            uint32_t lo = (b1 >> (8 * i)) & 1u ? rw : lw3;
+            uint32_t hi = (AH >> (8 * i)) & 255u;
+            if (E[4 * g + i] != 0ull && !((b0 >> (8 * i)) & 1u)) { lo = rlo[i]; hi = 0; }
+            const uint32_t sh = (o & 3u) * 8u;
+            const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
+            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
+            if (n) {
+                __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (E[4 * g + i] != 0ull && __ballot(rbig[i] != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
+                if (rbig[i]) {
+                    const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
+                    for (uint32_t t = 0; t <= q; ++t) {
+                        const uint32_t ob = o + t;
+                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+        }
+    }
+    return sbase;
+}
+
 template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
@@ -150,15 +289,36 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
     const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane
 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;
+    // Loads of one sub-tile.  The common shapes (sub-tile fully inside the image, 4- or 3-byte pixels) are
+    // straight-line so that all ten loads are in flight together and nothing waits until first use; a
+    // bounds test or a channel switch per load would put an s_waitcnt vmcnt(0) behind every one of them.
     auto load_sub = [&](uint32_t j, uint32_t (&px)[ENC_S], uint32_t& pb, uint32_t& pa) {
         const uint32_t base = j * ENC_SUB;
+        if (base > 0 && base + ENC_SUB < N && ch == 4) {
+            gcptr32 p = (gcptr32)src + base;
 #pragma unroll
-        for (int s = 0; s < ENC_S; ++s) {
-            const uint32_t idx = base + s * 64 + lane;
-            px[s] = idx < N ? load_px(src, idx, ch) : 0u;
+            for (int s = 0; s < ENC_S; ++s) px[s] = p[s * 64 + lane];
+            pb = p[-1];
+            pa = p[ENC_SUB];
+        } else if (base > 0 && base + ENC_SUB < N && ch == 3) {
+            gcptr8 p = src + (size_t)base * 3;
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                gcptr8 q = p + (s * 64 + lane) * 3;
+                px[s] = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | 0xff000000u;
+            }
+            pb = (uint32_t)p[-3] | (uint32_t)p[-2] << 8 | (uint32_t)p[-1] << 16 | 0xff000000u;
+            gcptr8 q = p + ENC_SUB * 3;
+            pa = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | 0xff000000u;
+        } else {
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                const uint32_t idx = base + s * 64 + lane;
+                px[s] = idx < N ? load_px(src, idx, ch) : 0u;
+            }
+            pb = base ? load_px(src, base - 1, ch) : kPxInit;
+            pa = base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u;
         }
-        pb = base ? load_px(src, base - 1, ch) : kPxInit;
-        pa = base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u;
     };
 
     uint32_t j = w;
@@ -241,8 +401,11 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         }
 
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
-        uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t sbase = 0;    // bytes staged so far
+        if (!QOI && !mono && base + ENC_SUB <= N) {
+            sbase = swar_main_pass(cur, E, c_in, pb, pa, has_after, stage, lane, le_mask);
+        } else {
+        uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t carry = pb;
 #pragma unroll
         for (int s = 0; s < ENC_S; ++s) {
@@ -316,6 +479,7 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
                 }
             }
             crun = e == ~0ull ? crun + 64u : (uint32_t)__builtin_clzll(~e);
+        }
         }
 
         // ---- output position from the chain, then drain the staging buffer -------------
