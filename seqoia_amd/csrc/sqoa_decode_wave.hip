@@ -184,13 +184,22 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 
     uint32_t* lds = s_bytes[w];
     uint32_t stg[3];
+    // straight-line when the whole staging window lies inside the stream (all but the last chunks): three
+    // loads in flight, no wait until the next iteration stages them
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[3]) {
         const uint32_t gs = p0 + c * DEC_CHUNK;
         const uint32_t d0 = gs >> 2;
+        if ((d0 + DEC_LDS_DW) * 4u <= size) {
+            gcptr32 p = (gcptr32)src + d0;
+            r[0] = p[lane];
+            r[1] = p[lane + 64];
+            r[2] = p[128 + (lane & 7)];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t d = d0 + lane + 64 * k;
-            r[k] = (k < 2 || lane < DEC_LDS_DW - 128) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t d = d0 + lane + 64 * k;
+                r[k] = (k < 2 || lane < DEC_LDS_DW - 128) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+            }
         }
     };
 

@@ -135,21 +135,16 @@ SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long 
     return o;
 }
 
-SQOA_DEV uint32_t swar_main_pass(const uint32_t (&cur)[ENC_S], const unsigned long long (&E)[ENC_S], uint32_t c_in, uint32_t pb,
-                                 uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask) {
+struct SwarGroup { uint32_t L0, L1, L2, TG, AH, b0, b1, Nn; };
+
+// Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
+SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
     const uint32_t H = sconst<0x80808080u>(), L = sconst<0x7f7f7f7fu>();
     const uint32_t C08 = sconst<0x08080808u>(), C20 = sconst<0x20202020u>(), C10 = sconst<0x10101010u>();
     const uint32_t MF0 = sconst<0xf0f0f0f0u>(), MC0 = sconst<0xc0c0c0c0u>(), ME0 = sconst<0xe0e0e0e0u>(), M0F = sconst<0x0f0f0f0fu>();
-    const uint32_t C60 = sconst<0x60606060u>(), CFE = sconst<0xfefefefeu>(), ONES = sconst<0x01010101u>();
+    const uint32_t C60 = sconst<0x60606060u>(), CFE = sconst<0xfefefefeu>();
     auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
     auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
-
-    uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
-    cr[0] = c_in;
-#pragma unroll
-    for (int s = 0; s < ENC_S; ++s) cr[s + 1] = E[s] == ~0ull ? cr[s] + 64u : (uint32_t)__builtin_clzll(~E[s]);
-
-    uint32_t sbase = 0;
     uint32_t c0 = pb;  // pixel in front of the group's first row
 #pragma unroll
     for (int g = 0; g < ENC_S / 4; ++g) {
@@ -174,20 +169,58 @@ SQOA_DEV uint32_t swar_main_pass(const uint32_t (&cur)[ENC_S], const unsigned lo
         const uint32_t b0 = nz(DR | DG | DB | DA) >> 7;                         // 1 = differs from its predecessor
         const uint32_t b1 = nz(bad) >> 7, b2 = nz(DA) >> 7;                     // 1 = needs RGB/RGBA; 1 = alpha moved
         const uint32_t na_mask = (b2 << 8) - b2, raw_mask = (b1 << 8) - b1;     // 0xff where set
-        const uint32_t L0 = XG | H;                                             // LUMA byte 0 (seqoia.h:612)
-        const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);                     // LUMA byte 1 (seqoia.h:614)
-        const uint32_t L2 = (XA | C60) & na_mask;                               // ALPHA suffix (seqoia.h:617)
-        const uint32_t TG = CFE | b2;                                           // RGB / RGBA tag (seqoia.h:622)
-        const uint32_t AH = A & na_mask & raw_mask;                             // 5th byte of RGBA
-        uint32_t Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);                      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+        SwarGroup& o = grp[g];
+        o.L0 = XG | H;                                   // LUMA byte 0 (seqoia.h:612)
+        o.L1 = ((XR << 4) & MF0) | (XB & M0F);           // LUMA byte 1 (seqoia.h:614)
+        o.L2 = (XA | C60) & na_mask;                     // ALPHA suffix (seqoia.h:617)
+        o.TG = CFE | b2;                                 // RGB / RGBA tag (seqoia.h:622)
+        o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
+        o.b0 = b0;
+        o.b1 = b1;
+        o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+#pragma unroll
+        for (int i = 0; i < 4; ++i) E[4 * g + i] = __ballot((b0 & (1u << (8 * i))) == 0u);
+    }
+}
 
+// Phase B: run bytes, byte offsets (two DPP prefix sums per four rows) and staging into LDS.
+SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
+                            uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask) {
+    uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
+    cr[0] = c_in;
+#pragma unroll
+    for (int s = 0; s < ENC_S; ++s) cr[s + 1] = E[s] == ~0ull ? cr[s] + 64u : (uint32_t)__builtin_clzll(~E[s]);
+    uint32_t sbase = 0;
+#pragma unroll
+    for (int g = 0; g < ENC_S / 4; ++g) {
+        const SwarGroup& G = grp[g];
+        uint32_t Nn = G.Nn;
         // pixels that repeat their predecessor: run bookkeeping per row, skipped for rows without any
         uint32_t rlo[4] = {0, 0, 0, 0}, rbig[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = 4 * g + i;
             const unsigned long long e = E[s];
-            if (e != 0ull) {
+            if (e == ~0ull) {
+                // the whole row continues one run: at most one 0xfd (the lane where k mod 512 == 0) and, on lane 63,
+                // the flush or the trailing 0xfd -- all of it wave-uniform arithmetic
+                const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
+                const bool end_px = s == ENC_S - 1 && !has_after;
+                const uint32_t r0 = cr[s] & 511u, r63 = (r0 + 64u) & 511u;
+                const uint32_t fd_lane = 511u - r0;                       // < 64 iff the run crosses a multiple of 512 here
+                uint32_t n63 = 0, lo63 = 0, big63 = 0;
+                if (r63 != 0u && (end_px || !nb)) {
+                    const uint32_t q = end_px ? 0u : ((r63 - 1u) * 1075u) >> 16;
+                    const uint32_t last = end_px ? 0xfdu : 0xc0u | (r63 - 1u - 61u * q);
+                    n63 = q + 1u;
+                    lo63 = q ? 0u : last;
+                    big63 = q ? (q << 8 | last) : 0u;
+                }
+                const bool is63 = lane == 63, isfd = (uint32_t)lane == fd_lane;
+                rlo[i] = isfd ? 0xfdu : is63 ? lo63 : 0u;
+                rbig[i] = is63 ? big63 : 0u;
+                Nn += (isfd ? 1u : is63 ? n63 : 0u) << (8 * i);
+            } else if (e != 0ull) {
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
                 const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
                 const RunOut ro = run_row(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
@@ -196,40 +229,43 @@ SQOA_DEV uint32_t swar_main_pass(const uint32_t (&cur)[ENC_S], const unsigned lo
                 Nn += ro.n << (8 * i);
             }
         }
-
-        // byte offsets: two DPP prefix sums over 16-bit fields cover the four rows
         const uint32_t i01 = wave_incl_scan(__builtin_amdgcn_perm(Nn, Nn, 0x0c010c00u));
         const uint32_t i23 = wave_incl_scan(__builtin_amdgcn_perm(Nn, Nn, 0x0c030c02u));
         const uint32_t t01 = bcast_lane(i01, 63), t23 = bcast_lane(i23, 63);
         const uint32_t rowbase[4] = {sbase, sbase + (t01 & 0xffffu), sbase + (t01 & 0xffffu) + (t01 >> 16),
                                      sbase + (t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu)};
         sbase = rowbase[3] + (t23 >> 16);
-        const uint32_t Pn[4] = {P0, P1, P2, P3};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t n = (Nn >> (8 * i)) & 255u;
             const uint32_t incl = ((i < 2 ? i01 : i23) >> (16 * (i & 1))) & 0xffffu;
             const uint32_t o = rowbase[i] + incl - n;
-            const uint32_t lw = __builtin_amdgcn_perm(L1, L0, 0x0c0c0400u + i * 0x0101u);           // L0.i, L1.i, 0, 0
-            const uint32_t lw3 = __builtin_amdgcn_perm(L2, lw, 0x0c040100u + i * 0x10000u);         // + L2.i
-            const uint32_t rw = __builtin_amdgcn_perm(Pn[i], TG, 0x06050400u + i);                  // tag, r, g, b
-            uint32_t lo = (b1 >> (8 * i)) & 1u ? rw : lw3;
-            uint32_t hi = (AH >> (8 * i)) & 255u;
-            if (E[4 * g + i] != 0ull && !((b0 >> (8 * i)) & 1u)) { lo = rlo[i]; hi = 0; }
+            const uint32_t lw = __builtin_amdgcn_perm(G.L1, G.L0, 0x0c0c0400u + i * 0x0101u);           // L0.i, L1.i, 0, 0
+            const uint32_t lw3 = __builtin_amdgcn_perm(G.L2, lw, 0x0c040100u + i * 0x10000u);           // + L2.i
+            const uint32_t rw = __builtin_amdgcn_perm(cur[4 * g + i], G.TG, 0x06050400u + i);           // tag, r, g, b
+            uint32_t lo = (G.b1 >> (8 * i)) & 1u ? rw : lw3;
+            uint32_t hi = (G.AH >> (8 * i)) & 255u;
             const uint32_t sh = (o & 3u) * 8u;
-            const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
             uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
-            if (n) {
+            if (E[4 * g + i] == 0ull) {  // every pixel of the row emits a literal op
+                const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
                 __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            if (E[4 * g + i] != 0ull && __ballot(rbig[i] != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
-                if (rbig[i]) {
-                    const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
-                    for (uint32_t t = 0; t <= q; ++t) {
-                        const uint32_t ob = o + t;
-                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                if (!((G.b0 >> (8 * i)) & 1u)) { lo = rlo[i]; hi = 0; }
+                const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
+                if (n) {
+                    __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                if (__ballot(rbig[i] != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
+                    if (rbig[i]) {
+                        const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
+                        for (uint32_t t = 0; t <= q; ++t) {
+                            const uint32_t ob = o + t;
+                            __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
                     }
                 }
             }
@@ -335,9 +371,12 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         const bool has_after = base + ENC_SUB < N;
         const bool last_sub = j == nsub - 1;
 
-        // ---- pre-pass: equality masks, local run aggregate -----------------------------
+        // ---- pre-pass: equality masks (from the SWAR classification on the fast path), local run aggregate ----
         unsigned long long E[ENC_S];
-        {
+        const bool swar = !QOI && !mono && base + ENC_SUB <= N;
+        SwarGroup grp[ENC_S / 4];
+        if (swar) swar_classify(cur, pb, grp, E);
+        else {
             uint32_t carry = pb;
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) {
@@ -402,8 +441,8 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
         uint32_t sbase = 0;    // bytes staged so far
-        if (!QOI && !mono && base + ENC_SUB <= N) {
-            sbase = swar_main_pass(cur, E, c_in, pb, pa, has_after, stage, lane, le_mask);
+        if (swar) {
+            sbase = swar_emit(cur, grp, E, c_in, pa, has_after, stage, lane, le_mask);
         } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t carry = pb;
