@@ -167,8 +167,9 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
         const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
         const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
         const uint32_t b0 = nz(DR | DG | DB | DA) >> 7;                         // 1 = differs from its predecessor
-        const uint32_t b1 = nz(bad) >> 7, b2 = nz(DA) >> 7;                     // 1 = needs RGB/RGBA; 1 = alpha moved
-        const uint32_t na_mask = (b2 << 8) - b2, raw_mask = (b1 << 8) - b1;     // 0xff where set
+        const uint32_t z1 = nz(bad), z2 = nz(DA);
+        const uint32_t b1 = z1 >> 7, b2 = z2 >> 7;                              // 1 = needs RGB/RGBA; 1 = alpha moved
+        const uint32_t na_mask = (z2 - b2) | z2, raw_mask = (z1 - b1) | z1;     // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
         SwarGroup& o = grp[g];
         o.L0 = XG | H;                                   // LUMA byte 0 (seqoia.h:612)
         o.L1 = ((XR << 4) & MF0) | (XB & M0F);           // LUMA byte 1 (seqoia.h:614)

@@ -181,3 +181,25 @@ def test_mixed_size_suite_in_one_plan(sq, orc, mode):
             assert res["status"][k] == 0 and got[k] == want, shapes[k]
     assert res["status"][len(shapes)] == 1 and res["len"][len(shapes)] == 0
     plan.close()
+
+
+def test_legacy_api_is_reentrant_across_threads(sq, orc):
+    """The reference keeps no state between calls (seqoia.h:439), so callers may use it from any thread;
+    the shim keeps one device context per thread.  16 threads encode + decode different images at once."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    o = orc.best()
+
+    def work(k):
+        w, h, ch = 100 + 7 * k, 50 + k, (3, 4)[k & 1]
+        px = orc.synth(w, h, ch, ("mixed", "icon", "photo")[k % 3], 4, k)
+        ok = True
+        for mode in (0, 1):
+            enc = sq.encode(px, sq.Desc(w, h, ch, 0, mode))
+            ok &= enc == o.encode(px, w, h, ch, mode)
+            out, d = sq.decode(enc, 0)
+            ok &= out is not None and out.tobytes() == px.tobytes()
+        return ok
+
+    with ThreadPoolExecutor(16) as ex:
+        assert all(ex.map(work, range(48)))
