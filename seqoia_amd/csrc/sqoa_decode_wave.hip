@@ -6,7 +6,7 @@
 // exact serial kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
 //
 // Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W, and
-// inside a chunk every lane owns 8 consecutive stream bytes):
+// inside a chunk every lane owns DEC_LB consecutive stream bytes):
 //   1. parse: every byte gets a transition function over the 7 parser states
 //      {A: op boundary after an op, N: op boundary where an ALPHA suffix is not allowed,
 //       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes, composition is two
@@ -18,13 +18,19 @@
 //      absolute ops (RGB/RGBA) re-base the sums through __ballot + ds_bpermute.
 //   3. (pixel position, pixel value) entering the chunk arrive through the LDS chain; literal ops
 //      store their pixel directly, runs are expanded cooperatively by the whole wave.
+#include <type_traits>
+
 #include "sqoa_common.h"
 
 namespace sqoa {
 
-constexpr int DEC_S = 8;
-constexpr int DEC_CHUNK = DEC_S * 64;     // stream bytes per chunk
-constexpr int DEC_LDS_DW = 136;           // staged dwords per wave: 512 + 8 look-ahead + 3 misalignment, rounded
+#ifndef SQOA_DEC_LB
+#define SQOA_DEC_LB 8  /* 16 halves the per-chunk scans but costs occupancy (109 VGPRs): 9.8 ms vs 7.2 ms */
+#endif
+constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane
+constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step)
+constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded
+constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
 constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 constexpr uint32_t ID_LO = 0x03020100u, ID_HI = 0x07060504u;  // identity transition function
 
@@ -118,7 +124,6 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
     return T;
 }
 
-constexpr int DEC_LB = 8;  // stream bytes owned by one lane (64 lanes x 8 = one 512-byte chunk per step)
 
 template <int W>
 __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
@@ -183,22 +188,22 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
     uint32_t bad = 0;
 
     uint32_t* lds = s_bytes[w];
-    uint32_t stg[3];
+    uint32_t stg[DEC_NLD];
     // straight-line when the whole staging window lies inside the stream (all but the last chunks): three
     // loads in flight, no wait until the next iteration stages them
-    auto load_chunk = [&](uint32_t c, uint32_t (&r)[3]) {
+    auto load_chunk = [&](uint32_t c, uint32_t (&r)[DEC_NLD]) {
         const uint32_t gs = p0 + c * DEC_CHUNK;
         const uint32_t d0 = gs >> 2;
         if ((d0 + DEC_LDS_DW) * 4u <= size) {
             gcptr32 p = (gcptr32)src + d0;
-            r[0] = p[lane];
-            r[1] = p[lane + 64];
-            r[2] = p[128 + (lane & 7)];
+#pragma unroll
+            for (int k = 0; k < DEC_NLD - 1; ++k) r[k] = p[lane + 64 * k];
+            r[DEC_NLD - 1] = p[64 * (DEC_NLD - 1) + (lane & 7)];
         } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < DEC_NLD; ++k) {
                 const uint32_t d = d0 + lane + 64 * k;
-                r[k] = (k < 2 || lane < DEC_LDS_DW - 128) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+                r[k] = (k < DEC_NLD - 1 || lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
             }
         }
     };
@@ -208,9 +213,9 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 
     for (; c < nchunks; c += W) {
         // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
-        lds[lane] = stg[0];
-        lds[lane + 64] = stg[1];
-        if (lane < DEC_LDS_DW - 128) lds[lane + 128] = stg[2];
+#pragma unroll
+        for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
+        if (lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) lds[lane + 64 * (DEC_NLD - 1)] = stg[DEC_NLD - 1];
         const bool more = c + W < nchunks;
         if (more) load_chunk(c + W, stg);
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
@@ -222,12 +227,12 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)DEC_LB ? (uint32_t)DEC_LB : chunks_len - my0);
 
         // ---- 1. parse: each lane composes the transition functions of its 8 bytes, one wave scan ----
-        unsigned long long q0;
-        __builtin_memcpy(&q0, lb, 8);
+        uint32_t qd[DEC_LB / 4];
+        __builtin_memcpy(qd, lb, DEC_LB);
         Fn F{ID_LO, ID_HI};
 #pragma unroll
         for (int k = 0; k < DEC_LB; ++k) {
-            const uint32_t b = (uint32_t)(q0 >> (8 * k)) & 0xffu;
+            const uint32_t b = (qd[k / 4] >> (8 * (k & 3))) & 0xffu;
             const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
             F = compose(Fn{flo, 0x07060403u}, F);
         }
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         const uint32_t lst = apply(Fx, st_in);  // parser state in front of my first byte
         // first op start: inside an op -> skip its remaining bytes; an ALPHA byte at an op boundary after an
         // op belongs to that op (whoever owns the op has read it), so it is skipped too
-        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? 8u : 0u);
+        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u);
         bool sfx_ok = lst != ST_N;  // may the byte at `pos` be an ALPHA suffix of the op before it?
         uint32_t val[DEC_LB];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
         uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13 | abs flags << 30
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
             unsigned long long q;
-            __builtin_memcpy(&q, lb + (pos < 8u ? pos : 8u), 8);  // op byte, <= 4 data bytes, possible ALPHA suffix
+            __builtin_memcpy(&q, lb + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB), 8);  // op byte, <= 4 data bytes, possible ALPHA suffix
             uint32_t b0 = (uint32_t)q & 0xffu;
             if (sfx_ok && (b0 - 0x60u) < 0x20u) { pos += 1u; q >>= 8; b0 = (uint32_t)q & 0xffu; }  // only possible for i == 0
             const bool act = pos < nlive;
@@ -272,24 +277,21 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             const uint32_t sb = (uint32_t)(q >> (8u * len)) & 0xffu;  // byte after the op (seqoia.h:777-783)
             const bool has_sfx = (sb - 0x60u) < 0x20u;
             const uint32_t da = has_sfx ? ((sb & 31u) - 16u) & 0xffu : 0u;
-            uint32_t cnt = 1, d8 = da << 24, setm = 0, base = 0;
-            if (b0 >= 0xfeu) {
-                setm = b0 == 0xffu ? 0xffffffffu : 0x00ffffffu;
-                base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;
-                if (b0 == 0xffu) d8 = 0;
-            } else if ((b0 & 0xc0u) == 0x80u) {  // LUMA, seqoia.h:761-769
-                const uint32_t vg = (b0 & 0x3fu) - 32u;
-                d8 |= ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
-            } else {                            // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775)
-                cnt = b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u;
-            }
-            if (act) {
-                T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm});
-                val[i] = T.v;
-                meta[i] = cl | cnt << 13 | (T.abs & 1u) << 30 | (T.abs >> 31) << 31;
-                cl += cnt;
-                pos += len + (has_sfx ? 1u : 0u);
-            } else { val[i] = 0; meta[i] = 0; }
+            // branch-free decode of the three op families (divergent branches cost more issue slots than the selects)
+            const bool is_abs = b0 >= 0xfeu, is_luma = (b0 & 0xc0u) == 0x80u;
+            const uint32_t setm = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
+            const uint32_t base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;  // RGB[A], seqoia.h:740-752
+            const uint32_t vg = (b0 & 0x3fu) - 32u;                                                   // LUMA, seqoia.h:761-769
+            const uint32_t dl = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
+            const uint32_t d8 = (is_luma ? dl : 0u) | da << 24;
+            // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775); everything else is one pixel
+            const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+            const uint32_t on = act ? 0xffffffffu : 0u;  // lanes that have run out of ops apply the identity
+            T = xf_then(T, Xf{((d8 & ~setm) | (base & setm)) & on, setm & on});
+            val[i] = T.v;
+            meta[i] = cl | (cnt & on) << 13 | (T.abs & 1u) << 30 | (T.abs >> 31) << 31;
+            cl += cnt & on;
+            pos += (len + (has_sfx ? 1u : 0u)) & on;
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
         if (ref_seen) {
@@ -317,29 +319,33 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         if (pos_in < N) {
             const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
+            auto store_ops = [&](auto oc_tag) {
+                constexpr int OC = decltype(oc_tag)::value;
 #pragma unroll
-            for (int i = 0; i < DEC_LB; ++i) {
-                const uint32_t m = meta[i];
-                const uint32_t cnt = (m >> 13) & 0x3ffu;
-                if (__ballot(cnt != 0u) == 0ull) break;
-                const uint32_t P = lane_p + (m & 0x1fffu);
-                const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
-                const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
-                if (cnt == 1u && P < N) {
-                    if (oc == 4) ((gptr32)out)[P] = v;
-                    else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                for (int i = 0; i < DEC_LB; ++i) {
+                    const uint32_t m = meta[i];
+                    const uint32_t cnt = (m >> 13) & 0x3ffu;
+                    if (__ballot(cnt != 0u) == 0ull) break;
+                    const uint32_t P = lane_p + (m & 0x1fffu);
+                    const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
+                    const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
+                    if (cnt == 1u && P < N) {
+                        if (OC == 4) ((gptr32)out)[P] = v;
+                        else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                    }
+                    unsigned long long runs = __ballot(cnt > 1u && P < N);
+                    while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
+                        const int l = __builtin_ctzll(runs);
+                        runs &= runs - 1ull;
+                        const uint32_t rp = bcast_lane(P, l), rv = bcast_lane(v, l);
+                        uint32_t rc = bcast_lane(cnt, l);
+                        if (rp + rc > N) rc = N - rp;
+                        fill_pixels<OC>(out, rp, rc, rv, lane);
+                    }
                 }
-                unsigned long long runs = __ballot(cnt > 1u && P < N);
-                while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
-                    const int l = __builtin_ctzll(runs);
-                    runs &= runs - 1ull;
-                    const uint32_t rp = bcast_lane(P, l), rv = bcast_lane(v, l);
-                    uint32_t rc = bcast_lane(cnt, l);
-                    if (rp + rc > N) rc = N - rp;
-                    if (oc == 4) fill_pixels<4>(out, rp, rc, rv, lane);
-                    else fill_pixels<3>(out, rp, rc, rv, lane);
-                }
-            }
+            };
+            if (oc == 4) store_ops(std::integral_constant<int, 4>{});
+            else store_ops(std::integral_constant<int, 3>{});
         }
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
