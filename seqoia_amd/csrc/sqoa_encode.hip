@@ -376,7 +376,18 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         unsigned long long E[ENC_S];
         const bool swar = !QOI && !mono && base + ENC_SUB <= N;
         SwarGroup grp[ENC_S / 4];
-        if (swar) swar_classify(cur, pb, grp, E);
+        // a sub-tile that is one solid run (flat areas of icons / screenshots) needs no per-pixel work at all
+        bool flat = false;
+        if (swar) {
+            uint32_t dif = 0;
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+            flat = __ballot(dif != 0u) == 0ull;
+        }
+        if (flat) {
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) E[s] = ~0ull;
+        } else if (swar) swar_classify(cur, pb, grp, E);
         else {
             uint32_t carry = pb;
 #pragma unroll
@@ -442,7 +453,33 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
         uint32_t sbase = 0;    // bytes staged so far
-        if (swar) {
+        if (flat) {
+            // k runs over c_in+1 .. c_in+512: exactly one of them is a multiple of 512 (0xfd, seqoia.h:546-549); the
+            // last pixel additionally owns the flush (seqoia.h:554-561) or the trailing 0xfd (seqoia.h:640-642)
+            const uint32_t r0 = c_in & 511u;              // the 0xfd falls on pixel 511 - r0; afterwards the remainder is r0
+            const bool end_px = !has_after;
+            const bool next_eq = has_after && pa == pb;
+            unsigned long long v = 0xfdull;
+            uint32_t nbytes = 1, b9 = 0;
+            if (r0 != 0u && (end_px || !next_eq)) {
+                if (end_px) { v |= 0xfdull << 8; nbytes = 2; }
+                else {
+                    const uint32_t q = ((r0 - 1u) * 1075u) >> 16;
+                    const uint32_t last = 0xc0u | (r0 - 1u - 61u * q);
+                    const unsigned long long fc = 0xfcfcfcfcfcfcfcfcull;
+                    const unsigned long long f = q >= 7 ? fc : ((fc & ((1ull << (8u * q)) - 1ull)) | (unsigned long long)last << (8u * q));
+                    v |= f << 8;                               // bytes 1..7 of the 64-bit word
+                    if (q >= 7) b9 = q == 7 ? last : (0xfcu | last << 8);  // bytes 8 (and 9) do not fit the word
+                    nbytes = q + 2u;
+                }
+            }
+            if (lane == 0) {  // position-independent staging: the bytes start at offset 0 of the (zeroed) buffer
+                reinterpret_cast<uint32_t*>(stage)[0] = (uint32_t)v;
+                reinterpret_cast<uint32_t*>(stage)[1] = (uint32_t)(v >> 32);
+                reinterpret_cast<uint32_t*>(stage)[2] = b9;
+            }
+            sbase = nbytes;
+        } else if (swar) {
             sbase = swar_emit(cur, grp, E, c_in, pa, has_after, stage, lane, le_mask);
         } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step

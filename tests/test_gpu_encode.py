@@ -203,3 +203,34 @@ def test_legacy_api_is_reentrant_across_threads(sq, orc):
 
     with ThreadPoolExecutor(16) as ex:
         assert all(ex.map(work, range(48)))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_long_runs_across_subtiles(sq, orc, mode):
+    """Runs that span many 512-pixel sub-tiles (flat areas): every remainder class of the flush
+    (0, 1..61, 62.., 488, 489..511 -> 1..9 bytes), the 0xfd at each 512th pixel, trailing runs,
+    runs starting at the image start with the implicit (0,0,0,255) pixel."""
+    import torch
+
+    o = orc.best()
+    imgs = []
+    rng = np.random.default_rng(5)
+    for lead in (0, 1, 3, 200, 511, 512, 513):
+        for run in (511, 512, 513, 1023, 1024, 1025, 1535, 1536 + 61, 1536 + 62, 2048 + 488, 2048 + 489, 2048 + 511, 4096, 5000):
+            for tail in (0, 1, 700):
+                px = np.zeros((lead + run + tail, 4), np.uint8)
+                px[:lead] = rng.integers(0, 256, size=(lead, 4))
+                px[lead:lead + run] = (0, 0, 0, 255) if (lead == 0 and run % 2) else (17, 99, 200, 255)
+                px[lead + run:] = rng.integers(0, 256, size=(tail, 4))
+                if tail and (px[lead + run] == px[lead + run - 1]).all():
+                    px[lead + run, 0] ^= 1
+                imgs.append(px)
+    images = [(torch.from_numpy(p.reshape(-1)).cuda(), sq.Desc(p.shape[0], 1, 4, 0, mode)) for p in imgs]
+    plan = sq.EncodeList(images)
+    plan.launch()
+    res = plan.results()
+    got = plan.streams()
+    for k, p in enumerate(imgs):
+        want = o.encode(p.reshape(-1), p.shape[0], 1, 4, mode)
+        assert res["status"][k] == 0 and got[k] == want, (k, p.shape[0])
+    plan.close()
