@@ -121,3 +121,110 @@ def test_batch_decode_mutants_match_oracle(sq, orc):
             assert res["status"][i] == 0, i
             assert out[i].tobytes() == want.tobytes(), i
     dec.close()
+
+
+def test_wave_decoder_chunk_boundaries(sq, orc):
+    """Crafted multi-chunk SQOA streams (the wave decoder cuts the stream every 512 bytes, 8 bytes per lane):
+    every alignment of 1/2/3/4/5/6-byte ops against lane and chunk boundaries, ALPHA suffix as first byte of a
+    lane / chunk, op bytes that look like op starts, REF op deep in the stream (hand-over to the serial kernel
+    while other waves wait), stream exhausted in the middle of an op."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(77)
+
+    def hdr(w, h, ch=4):
+        return b"Sqoa" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0, 0x31])
+
+    def body(n_ops, kinds):
+        out = bytearray()
+        for _ in range(n_ops):
+            k = kinds[int(rng.integers(0, len(kinds)))]
+            if k == "luma":
+                out += bytes([0x80 | int(rng.integers(0, 64)), int(rng.integers(0, 256))])
+            elif k == "luma_a":
+                out += bytes([0x80 | int(rng.integers(0, 64)), int(rng.integers(0, 256)), 0x60 | int(rng.integers(0, 32))])
+            elif k == "rgb":
+                out += bytes([0xfe]) + bytes(rng.integers(0, 256, 3).tolist())
+            elif k == "rgb_a":
+                out += bytes([0xfe]) + bytes(rng.integers(0, 256, 3).tolist()) + bytes([0x60 | int(rng.integers(0, 32))])
+            elif k == "rgba":
+                out += bytes([0xff]) + bytes(rng.integers(0, 256, 4).tolist())
+            elif k == "rgba_a":
+                out += bytes([0xff]) + bytes(rng.integers(0, 256, 4).tolist()) + bytes([0x60 | int(rng.integers(0, 32))])
+            elif k == "run":
+                out += bytes([0xc0 | int(rng.integers(0, 61))])
+            elif k == "run_a":
+                out += bytes([0xc0 | int(rng.integers(0, 61)), 0x60 | int(rng.integers(0, 32))])
+            elif k == "bigrun":
+                out += b"\xfd"
+            elif k == "alpha_alpha":  # suffix, then a second 0x60..0x7f byte: a RUN op (seqoia.h:773-775)
+                out += bytes([0x80 | int(rng.integers(0, 64)), int(rng.integers(0, 256)), 0x65, 0x6a])
+        return bytes(out)
+
+    END = bytes(7) + b"\x01"
+    streams = []
+    mixes = [["luma"], ["luma", "luma_a"], ["rgb", "luma"], ["rgba", "luma_a", "run"], ["rgba_a", "rgb_a", "run_a", "alpha_alpha"],
+             ["run", "bigrun", "luma"], ["luma", "luma_a", "rgb", "rgb_a", "rgba", "rgba_a", "run", "run_a", "bigrun", "alpha_alpha"]]
+    for shift in range(9):  # leading run bytes move every later op by one byte
+        for mix in mixes:
+            streams.append(hdr(96, 64) + b"\xc0" * shift + body(700, mix) + END)
+    full = mixes[-1]
+    streams.append(hdr(96, 64) + body(500, full) + b"\x45" + body(300, full) + END)        # REF op in a later chunk
+    streams.append(hdr(96, 64) + body(400, ["luma"]) + b"\x1f" + body(10, full) + END)     # REF reaching back 31 bytes
+    streams.append((hdr(96, 64) + body(300, full) + END)[:-9])                             # exhausted: cut inside the tail
+    streams.append(hdr(96, 64) + body(300, full) + b"\xff\x01\x02")                        # exhausted inside an RGBA op
+    streams.append(hdr(96, 64) + b"\x6a" + body(300, full) + END)                          # leading ALPHA byte is a run
+    streams.append(hdr(300, 300) + body(40, ["bigrun", "run"]) + END)                      # runs overshoot the image
+    streams.append(hdr(96, 64, 3) + body(700, ["luma", "rgb", "run", "luma_a"]) + END)     # 3-channel file, 4-channel output
+    wants = [o.decode(s, 4) for s in streams]
+    slot = max(len(s) for s in streams) + 32
+    buf = np.zeros((len(streams), slot), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    t = torch.from_numpy(buf).cuda()
+    # every stream has its own geometry: one plan per geometry group would do; here one DecodePlan per stream size class
+    groups = {}
+    for i, s in enumerate(streams):
+        w, h = int.from_bytes(s[4:8], "big"), int.from_bytes(s[8:12], "big")
+        groups.setdefault((w, h), []).append(i)
+    for (w, h), idx in groups.items():
+        sub = t[idx].contiguous()
+        dec = sq.DecodePlan(sub, [len(streams[i]) for i in idx], w, h, 4)
+        dec.launch()
+        res = dec.results()
+        out = dec.out.cpu().numpy()
+        for k, i in enumerate(idx):
+            want, wd = wants[i]
+            if want is None:
+                assert res["status"][k] != 0, i
+            else:
+                assert res["status"][k] == 0, (i, int(res["status"][k]))
+                assert out[k].tobytes() == want.tobytes(), i
+        dec.close()
+
+
+def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
+    """BASELINE configs 2+3 at full size: 1024 x 1024x1024 RGBA.  Size-independent properties: every status
+    OK, decode(encode(px)) == px for the whole batch (sqoabench.c:448-455), total length of images 0-15 equal to
+    the reference's, and byte-for-byte equality with the oracle on a sample."""
+    import torch
+
+    n = 1024
+    px = torch.empty((n, 1024, 1024, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=1, img0=0)
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    enc.launch()
+    res = enc.results()
+    assert (res["status"] == 0).all()
+    assert int(res["len"][:16].sum()) == synth_digests["totals"]["mixed_1024_rgba_0_15"]["sqoa_total"]
+    dec = sq.DecodePlan(enc.out, res["len"], 1024, 1024, 4)
+    dec.launch()
+    dres = dec.results()
+    assert (dres["status"] == 0).all() and (dres["len"] == 4 << 20).all()
+    assert torch.equal(dec.out, px)
+    o = orc.best()
+    for k in (5, 511, 1023):
+        assert enc.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, 0)
+    dec.close()
+    enc.close()
