@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Time the decode plan only (no output check): for A/B runs of experimental builds via SQOA_LIB.
+The streams are produced by the default library's encoder so that every variant decodes the same bytes."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import seqoia_amd as sq
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=1024); ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--iters", type=int, default=5); ap.add_argument("--cls", default="mixed")
+a = ap.parse_args()
+px = torch.empty((a.images, a.size, a.size, 4), dtype=torch.uint8, device="cuda")
+sq.synth(px, a.cls, 1, 0)
+enc = sq.EncodePlan(px, qoi_compat=0)
+enc.launch(); res = enc.results()
+dec = sq.DecodePlan(enc.out, res["len"], a.size, a.size, 4)
+dec.launch(); dec.results()
+ms = dec.time(a.iters) / a.iters
+print(f"{os.environ.get('SQOA_LIB','default')} cls={a.cls} decode {ms:.3f} ms/launch  {a.images*a.size*a.size/ms/1e3:.0f} Mpx/s")
