@@ -91,8 +91,53 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
     uint32_t r = 0, g = 0, b = 0, a = 255;
     int run = 0;
     const int chunks_len = size - 8;
+    // Fast mode: while no SQOA_OP_REF has been met the cursor only moves forward, so one unaligned 8-byte load
+    // per op (op byte, <= 4 data bytes, ALPHA peek) replaces up to six dependent byte loads.  The first REF
+    // switches to the byte-exact cursor below for the rest of the stream (seqoia.h:418, :729-738).
+    bool exact = false;
     for (uint32_t i = 0; i < N; ++i) {
         if (run > 0) run--;
+        else if (c.p < chunks_len && !exact) {
+            unsigned long long q;
+            {
+                typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+                typedef const __attribute__((address_space(1))) u64_unaligned* gq;
+                gcptr8 a8 = bytes + c.p;
+                if (c.p + 8 <= size) q = *(gq)a8;
+                else { q = 0; for (int k = 0; k < 8 && c.p + k < size; ++k) q |= (unsigned long long)a8[k] << (8 * k); }
+            }
+            const int b1 = (int)(q & 0xff);
+            if (!qoi && b1 < 0x60) { exact = true; --i; continue; }  // REF: redo this pixel with the exact cursor
+            int used = 1;
+            if (b1 >= 0xfe) {  // seqoia.h:740-752
+                if (col == 3) { r = (q >> 8) & 255u; g = (q >> 16) & 255u; b = (q >> 24) & 255u; used = 4; }
+                else { g = (q >> 8) & 255u; used = 2; }
+                if (b1 == 0xff) { a = (q >> (8 * used)) & 255u; used++; }
+            } else if (qoi && (uint32_t)b1 < index_size) {  // seqoia.h:753-755
+                const uint32_t v = s_table[b1][t];
+                r = v & 255u; g = (v >> 8) & 255u; b = (v >> 16) & 255u; a = v >> 24;
+            } else if (qoi && (b1 & 0xc0) == 0x40) {  // seqoia.h:756-760
+                r = (r + ((b1 >> 4) & 3) - 2) & 255u;
+                g = (g + ((b1 >> 2) & 3) - 2) & 255u;
+                b = (b + (b1 & 3) - 2) & 255u;
+            } else if ((b1 & 0xc0) == 0x80) {  // seqoia.h:761-769
+                const int vg = (b1 & 0x3f) - 32;
+                g = (g + vg) & 255u;
+                if (col == 3) {
+                    const int b2 = (int)((q >> 8) & 255u);
+                    r = (r + vg - 8 + ((b2 >> 4) & 15)) & 255u;
+                    b = (b + vg - 8 + (b2 & 15)) & 255u;
+                    used = 2;
+                }
+            } else if (!qoi && b1 == 0xfd) run = 511;  // seqoia.h:770-772
+            else run = b1 & 0x3f;                        // seqoia.h:773-775
+            if (!qoi && col == 3) {  // ALPHA suffix, seqoia.h:777-783
+                const int pk = (int)((q >> (8 * used)) & 255u);
+                if (pk >= 0x60 && pk < 0x80) { a = (a + (pk & 31) - 16) & 255u; used++; }
+            }
+            c.p += used;
+            if (qoi) s_table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size][t] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
+        }
         else if (c.p < chunks_len) {
             int b1 = bytes[c.next()];
             if (!qoi && b1 < 0x60) {  // SQOA_OP_REF, seqoia.h:729-738
@@ -133,6 +178,11 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
             if (qoi) s_table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size][t] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
         }
         gptr8 o = out + (size_t)i * channels;  // seqoia.h:790-805
+        if (channels == 4 && (job.dst & 3ull) == 0) {
+            const uint32_t rr = col == 3 ? r : g, bb = col == 3 ? b : g;
+            ((gptr32)out)[i] = rr | g << 8 | bb << 16 | a << 24;
+            continue;
+        }
         if (channels >= 3 && col == 3) { o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
         else { o[0] = (uint8_t)g; if (channels >= 3) { o[1] = (uint8_t)g; o[2] = (uint8_t)g; } }
         if (add_alpha) o[channels - 1] = (uint8_t)a;
