@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--images", type=int, default=1024, help="images per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -88,12 +89,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    local = local % max(torch.cuda.device_count(), 1)  # rehearsal on a 1-GPU box: ranks share the device
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     n, s, ch = args.images, args.size, 4
     dev = torch.device("cuda", local)
@@ -139,7 +144,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
