@@ -135,7 +135,7 @@ SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long 
     return o;
 }
 
-struct SwarGroup { uint32_t L0, L1, L2, TG, AH, b0, b1, Nn; };
+struct SwarGroup { uint32_t W0, W1, W2, W3, AH, b0, Nn; };  // bytes 0..3 and 4 of every pixel's literal op (byte i = row i)
 
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
@@ -166,18 +166,22 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
         const uint32_t XR = sub8(DR, DGm), XB = sub8(DB, DGm);                  // vg_r + 8, vg_b + 8
         const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
         const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
-        const uint32_t b0 = nz(DR | DG | DB | DA) >> 7;                         // 1 = differs from its predecessor
-        const uint32_t z1 = nz(bad), z2 = nz(DA);
-        const uint32_t b1 = z1 >> 7, b2 = z2 >> 7;                              // 1 = needs RGB/RGBA; 1 = alpha moved
-        const uint32_t na_mask = (z2 - b2) | z2, raw_mask = (z1 - b1) | z1;     // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
+        const uint32_t z0 = nz(DR | DG | DB | DA), z1 = nz(bad), z2 = nz(DA);
+        const uint32_t b0 = z0 >> 7, b1 = z1 >> 7, b2 = z2 >> 7;   // 1 = differs from its predecessor; needs RGB/RGBA; alpha moved
+        // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
+        const uint32_t ne_mask = (z0 - b0) | z0, raw_mask = (z1 - b1) | z1, na_mask = (z2 - b2) | z2;
+        const uint32_t L0 = XG | H;                                  // LUMA byte 0 (seqoia.h:612)
+        const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);          // LUMA byte 1 (seqoia.h:614)
+        const uint32_t L2 = (XA | C60) & na_mask;                    // ALPHA suffix (seqoia.h:617)
+        const uint32_t TG = CFE | b2;                                // RGB / RGBA tag (seqoia.h:622)
         SwarGroup& o = grp[g];
-        o.L0 = XG | H;                                   // LUMA byte 0 (seqoia.h:612)
-        o.L1 = ((XR << 4) & MF0) | (XB & M0F);           // LUMA byte 1 (seqoia.h:614)
-        o.L2 = (XA | C60) & na_mask;                     // ALPHA suffix (seqoia.h:617)
-        o.TG = CFE | b2;                                 // RGB / RGBA tag (seqoia.h:622)
+        // the op's bytes, already chosen between LUMA[+ALPHA] and RGB[A]; zero for repeated pixels
+        o.W0 = ((L0 & ~raw_mask) | (TG & raw_mask)) & ne_mask;
+        o.W1 = ((L1 & ~raw_mask) | (R & raw_mask)) & ne_mask;
+        o.W2 = ((L2 & ~raw_mask) | (G & raw_mask)) & ne_mask;
+        o.W3 = B & raw_mask & ne_mask;
         o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
         o.b0 = b0;
-        o.b1 = b1;
         o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
 #pragma unroll
         for (int i = 0; i < 4; ++i) E[4 * g + i] = __ballot((b0 & (1u << (8 * i))) == 0u);
@@ -195,9 +199,10 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 #pragma unroll
     for (int g = 0; g < ENC_S / 4; ++g) {
         const SwarGroup& G = grp[g];
-        uint32_t Nn = G.Nn;
-        // pixels that repeat their predecessor: run bookkeeping per row, skipped for rows without any
-        uint32_t rlo[4] = {0, 0, 0, 0}, rbig[4] = {0, 0, 0, 0};
+        uint32_t Nn = G.Nn, W0 = G.W0;
+        // pixels that repeat their predecessor: run bookkeeping per row, skipped for rows without any;
+        // their (single) run byte joins byte plane 0, which is zero there
+        uint32_t rbig[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = 4 * g + i;
@@ -218,14 +223,14 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                     big63 = q ? (q << 8 | last) : 0u;
                 }
                 const bool is63 = lane == 63, isfd = (uint32_t)lane == fd_lane;
-                rlo[i] = isfd ? 0xfdu : is63 ? lo63 : 0u;
+                W0 |= (isfd ? 0xfdu : is63 ? lo63 : 0u) << (8 * i);
                 rbig[i] = is63 ? big63 : 0u;
                 Nn += (isfd ? 1u : is63 ? n63 : 0u) << (8 * i);
             } else if (e != 0ull) {
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
                 const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
                 const RunOut ro = run_row(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
-                rlo[i] = ro.lo;
+                W0 |= ro.lo << (8 * i);
                 rbig[i] = ro.big;
                 Nn += ro.n << (8 * i);
             }
@@ -236,25 +241,24 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
         const uint32_t rowbase[4] = {sbase, sbase + (t01 & 0xffffu), sbase + (t01 & 0xffffu) + (t01 >> 16),
                                      sbase + (t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu)};
         sbase = rowbase[3] + (t23 >> 16);
+        // back from byte planes to one dword per row: a 4x4 byte transpose (8 v_perm_b32, same selectors as the way in)
+        const uint32_t w01 = __builtin_amdgcn_perm(G.W1, W0, 0x05010400u), w23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x05010400u);
+        const uint32_t u01 = __builtin_amdgcn_perm(G.W1, W0, 0x07030602u), u23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x07030602u);
+        const uint32_t lo4[4] = {__builtin_amdgcn_perm(w23, w01, 0x05040100u), __builtin_amdgcn_perm(w23, w01, 0x07060302u),
+                                 __builtin_amdgcn_perm(u23, u01, 0x05040100u), __builtin_amdgcn_perm(u23, u01, 0x07060302u)};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t n = (Nn >> (8 * i)) & 255u;
             const uint32_t incl = ((i < 2 ? i01 : i23) >> (16 * (i & 1))) & 0xffffu;
             const uint32_t o = rowbase[i] + incl - n;
-            const uint32_t lw = __builtin_amdgcn_perm(G.L1, G.L0, 0x0c0c0400u + i * 0x0101u);           // L0.i, L1.i, 0, 0
-            const uint32_t lw3 = __builtin_amdgcn_perm(G.L2, lw, 0x0c040100u + i * 0x10000u);           // + L2.i
-            const uint32_t rw = __builtin_amdgcn_perm(cur[4 * g + i], G.TG, 0x06050400u + i);           // tag, r, g, b
-            uint32_t lo = (G.b1 >> (8 * i)) & 1u ? rw : lw3;
-            uint32_t hi = (G.AH >> (8 * i)) & 255u;
+            const uint32_t lo = lo4[i], hi = (G.AH >> (8 * i)) & 255u;
             const uint32_t sh = (o & 3u) * 8u;
+            const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
             uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
             if (E[4 * g + i] == 0ull) {  // every pixel of the row emits a literal op
-                const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
                 __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             } else {
-                if (!((G.b0 >> (8 * i)) & 1u)) { lo = rlo[i]; hi = 0; }
-                const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
                 if (n) {
                     __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
