@@ -63,6 +63,15 @@ SQOA_DEV Fn wave_compose_scan(Fn F) {
     return F;
 }
 
+// 8 stream bytes starting at byte offset `off` of a dword array in LDS.  Unaligned ds_read_b64 works on gfx950 but
+// stalls the LDS pipe (SQ_LDS_UNALIGNED_STALL); three aligned dwords and two v_alignbyte_b32 do not.
+SQOA_DEV unsigned long long lds_read8(const uint32_t* base, uint32_t off) {
+    const uint32_t* p = base + (off >> 2);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
+    return (unsigned long long)hi << 32 | lo;
+}
+
 // bytewise (mod 256) add / sub of four packed channels
 SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
 SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
@@ -261,8 +270,8 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         bool ref_seen = false;
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
-            unsigned long long q;
-            __builtin_memcpy(&q, lb + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB), 8);  // op byte, <= 4 data bytes, possible ALPHA suffix
+            // op byte, <= 4 data bytes, possible ALPHA suffix
+            unsigned long long q = lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB));
             uint32_t b0 = (uint32_t)q & 0xffu;
             if (sfx_ok && (b0 - 0x60u) < 0x20u) { pos += 1u; q >>= 8; b0 = (uint32_t)q & 0xffu; }  // only possible for i == 0
             const bool act = pos < nlive;
