@@ -228,3 +228,39 @@ def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
         assert enc.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, 0)
     dec.close()
     enc.close()
+
+
+def test_plans_replay_from_a_hip_graph(sq, orc):
+    """sqoa_hip_plan_launch does no allocation and no host sync, so an encode->decode step can be captured
+    once into a HIP graph and replayed: new pixels written into the same buffers re-encode / re-decode correctly."""
+    import torch
+
+    n, w, h = 32, 256, 256
+    px = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=1, img0=0)
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    enc.launch()
+    res = enc.results()
+    dec = sq.DecodePlan(enc.out, res["len"], w, h, 4)  # stream lengths are job-table constants: keep the content class
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        enc.launch(side.cuda_stream)  # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        enc.launch(side.cuda_stream)
+    o = orc.best()
+    for seed in (1, 2, 3):
+        sq.synth(px, "mixed", seed=seed, img0=0)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        r = enc.results()
+        assert (r["status"] == 0).all()
+        for k in (0, n - 1):
+            want = o.encode(orc.synth(w, h, 4, "mixed", seed, k), w, h, 4, 0)
+            assert bytes(enc.out[k, : int(r["len"][k])].cpu().numpy()) == want, (seed, k)
+    dec.close()
+    enc.close()
