@@ -93,6 +93,13 @@ int sqoa_hip_plan_results(sqoa_hip_plan *plan, sqoa_hip_result *out, int n);
  * events recorded on that stream; *ms_total receives the elapsed time. */
 int sqoa_hip_plan_time(sqoa_hip_plan *plan, int iters, float *ms_total);
 
+/* Exact-size container: after an encode plan has run, copy its n streams out of their
+ * worst-case slots into one tightly packed blob; offsets[i] .. offsets[i+1] (n+1 entries, device memory, bytes) is
+ * stream i (empty for failed jobs).  *total receives offsets[n].  Asynchronous on `stream` (NULL = the plan's) up to
+ * the final read-back of the total, which synchronises. */
+int sqoa_hip_pack(sqoa_hip_plan *plan, unsigned long long d_blob, size_t blob_cap, unsigned long long d_offsets,
+                  unsigned long long *total, void *stream);
+
 /* Synthetic images of SURVEY.md Appendix C written straight into HBM:
  * n images of w*h*channels bytes, image k = (cls, seed, img0 + k), packed at
  * dst + k*stride. cls: 0 mixed, 1 icon, 2 photo. */

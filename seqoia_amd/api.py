@@ -109,6 +109,20 @@ class Plan:
         check(self.lib.sqoa_hip_plan_time(self._h, iters, C.byref(ms)), "sqoa_hip_plan_time")
         return ms.value
 
+    def pack(self, stream: int = 0):
+        """Encode plans: tightly packed blob of all streams + int64 offsets [n+1] (torch CUDA tensors)."""
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        res = self.results()
+        cap = int(res["len"].astype(np.int64).sum())
+        blob = torch.empty((max(cap, 1),), dtype=torch.uint8, device=dev)
+        offsets = torch.empty((self.n + 1,), dtype=torch.int64, device=dev)
+        total = C.c_ulonglong(0)
+        check(self.lib.sqoa_hip_pack(self._h, blob.data_ptr(), cap, offsets.data_ptr(), C.byref(total),
+                                     C.c_void_p(stream) if stream else None), "sqoa_hip_pack")
+        return blob[: total.value], offsets
+
     def close(self):
         if self._h:
             self.lib.sqoa_hip_plan_destroy(self._h)

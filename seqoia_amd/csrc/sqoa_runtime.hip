@@ -272,6 +272,54 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ dst, s
     else { o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
 }
 
+// offsets[i] = sum of len[0..i): one workgroup walks the table in tiles of 1024 with a DPP/LDS block scan
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const sqoa_hip_result* __restrict__ res, int n, unsigned long long* __restrict__ offsets) {
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + t;
+        const unsigned long long v = i < n && res[i].status == 0 && res[i].len > 0 ? (unsigned long long)res[i].len : 0ull;
+        unsigned long long x = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wave[wv] = x;
+        __syncthreads();
+        unsigned long long pre = s_carry;
+        for (int k = 0; k < wv; ++k) pre += s_wave[k];
+        if (i < n) offsets[i] = pre + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (t == 0) offsets[n] = s_carry;
+}
+
+// one workgroup per stream: 16-byte loads from the (256-byte aligned) slot, unaligned 16-byte stores into the blob
+__global__ __launch_bounds__(256) void pack_copy_kernel(const sqoa_hip_job* __restrict__ jobs, const sqoa_hip_result* __restrict__ res,
+                                                        const unsigned long long* __restrict__ offsets, uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_cap) {
+    const int i = blockIdx.x;
+    const unsigned long long o0 = offsets[i], o1 = offsets[i + 1];
+    if (o1 <= o0 || o1 > blob_cap) return;
+    const uint32_t len = (uint32_t)(o1 - o0);
+    gcptr8 src = (gcptr8)jobs[i].dst;
+    gptr8 dst = (gptr8)(blob + o0);
+    if ((jobs[i].dst & 15ull) == 0) {
+        typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+        typedef __attribute__((address_space(1))) u32x4_unaligned* gptr128u;
+        const uint32_t nv = len >> 4;
+        for (uint32_t k = threadIdx.x; k < nv; k += blockDim.x) ((gptr128u)dst)[k] = ((gcptr128)src)[k];
+        for (uint32_t k = (nv << 4) + threadIdx.x; k < len; k += blockDim.x) dst[k] = src[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) dst[k] = src[k];
+    }
+}
+
 // One lane per buffer: FNV-1a is a serial chain; this is a checking aid, not a hot path.
 __global__ void fnv_kernel(const unsigned long long* __restrict__ ptrs, const uint32_t* __restrict__ lens, int n,
                            unsigned long long* __restrict__ out) {
@@ -300,6 +348,24 @@ int sqoa_hip_synth(int device, unsigned long long dst, size_t stride, unsigned w
     }
     HIP_TRY(hipGetLastError(), SQOA_HIP_ELAUNCH);
     HIP_TRY(hipDeviceSynchronize(), SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+int sqoa_hip_pack(sqoa_hip_plan* p, unsigned long long d_blob, size_t blob_cap, unsigned long long d_offsets,
+                  unsigned long long* total, void* stream) {
+    if (!p || p->kind != SQOA_HIP_ENCODE || !d_blob || !d_offsets) return fail(SQOA_HIP_EINVAL, "sqoa_hip_pack: bad arguments");
+    HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    unsigned long long* off = (unsigned long long*)(uintptr_t)d_offsets;
+    hipLaunchKernelGGL(sqoa::pack_offsets_kernel, dim3(1), dim3(1024), 0, s, p->d_results, p->n, off);
+    if (p->n) hipLaunchKernelGGL(sqoa::pack_copy_kernel, dim3(p->n), dim3(256), 0, s, p->d_jobs, p->d_results, off, (uint8_t*)(uintptr_t)d_blob,
+                                 (unsigned long long)blob_cap);
+    HIP_TRY(hipGetLastError(), SQOA_HIP_ELAUNCH);
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(total, off + p->n, sizeof(unsigned long long), hipMemcpyDeviceToHost, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(hipStreamSynchronize(s), SQOA_HIP_ELAUNCH);
+        if (*total > blob_cap) return fail(SQOA_HIP_ENOMEM, "sqoa_hip_pack: blob too small");
+    }
     return 0;
 }
 

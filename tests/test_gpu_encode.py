@@ -234,3 +234,28 @@ def test_long_runs_across_subtiles(sq, orc, mode):
         want = o.encode(p.reshape(-1), p.shape[0], 1, 4, mode)
         assert res["status"][k] == 0 and got[k] == want, (k, p.shape[0])
     plan.close()
+
+
+def test_pack_streams_into_exact_size_blob(sq, orc):
+    """SURVEY.md 8f-4: the worst-case slots compacted on the device into one blob + offset table;
+    the blob is the concatenation of the reference streams."""
+    import torch
+
+    o = orc.best()
+    shapes = [(64, 64, 4, "icon"), (333, 77, 4, "mixed"), (200, 150, 3, "photo"), (1, 1, 4, "mixed"), (512, 512, 3, "icon"), (800, 600, 4, "mixed")]
+    images, wants = [], []
+    for k, (w, h, c, cls) in enumerate(shapes):
+        raw = orc.synth(w, h, c, cls, 6, k)
+        images.append((torch.from_numpy(raw).cuda(), sq.Desc(w, h, c, 0, k & 1)))
+        wants.append(o.encode(raw, w, h, c, k & 1))
+    images.insert(2, (torch.zeros(4, dtype=torch.uint8, device="cuda"), sq.Desc(0, 1, 4, 0, 0)))  # refused job: empty entry
+    wants.insert(2, b"")
+    plan = sq.EncodeList(images)
+    plan.launch()
+    blob, offsets = plan.pack()
+    off = offsets.cpu().numpy()
+    data = bytes(blob.cpu().numpy())
+    assert off[0] == 0 and off[-1] == len(data) == sum(len(x) for x in wants)
+    for i, wnt in enumerate(wants):
+        assert data[off[i]:off[i + 1]] == wnt, i
+    plan.close()
