@@ -33,7 +33,7 @@ $(OUT)/libsqoa_mi355x.so: $(OBJS)
 oracle:
 	$(MAKE) -s -C oracle
 
-TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x
+TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x tools/bin/sqoabatch_mi355x
 tools: lib $(TOOLS)
 tools/bin/%: tools/%.c include/seqoia.h include/sqoa_hip.h
 	@mkdir -p tools/bin

@@ -49,3 +49,34 @@ def test_sqoabench_synth_runs_and_verifies():
     r = subprocess.run([bench, "2", "--synth", "mixed", "256", "256", "4", "16"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "sqoa-batch:" in r.stdout and "decode mpps" in r.stdout
+
+
+def test_sqoabatch_directory_roundtrip(tmp_path):
+    """Directory front-end on the batch C-ABI + sqoa_hip_pack: every file byte-identical to the reference's."""
+    from oracle import pyoracle as po
+
+    if not os.path.exists(os.path.join(BIN, "sqoabatch_mi355x")):
+        subprocess.run(["make", "-s", "-C", ROOT, "tools"], check=True)
+    batch = os.path.join(BIN, "sqoabatch_mi355x")
+    src, enc, qoi, back = tmp_path / "src", tmp_path / "enc", tmp_path / "qoi", tmp_path / "back"
+    for d in (src, enc, qoi, back):
+        d.mkdir()
+    imgs = {}
+    for k, (w, h, ch, cls) in enumerate([(64, 64, 4, "icon"), (300, 200, 3, "photo"), (513, 7, 4, "mixed"), (1024, 512, 4, "mixed"), (90, 90, 1, "photo")]):
+        px = po.synth(w, h, 4, cls, 8, k).reshape(-1, 4)
+        px = (px[:, :ch] if ch >= 3 else px[:, 1:2]).copy()
+        imgs[f"img{k}"] = (px, w, h, ch)
+        pam(src / f"img{k}.pam", px, w, h, ch)
+    assert subprocess.run([batch, "encode", str(src), str(enc)]).returncode == 0
+    for name, (px, w, h, ch) in imgs.items():
+        assert (enc / f"{name}.sqoa").read_bytes() == po.best().encode(px.reshape(-1), w, h, ch, 0), name
+    assert subprocess.run([batch, "decode", str(enc), str(back)]).returncode == 0
+    for name, (px, w, h, ch) in imgs.items():
+        assert (back / f"{name}.pam").read_bytes().split(b"ENDHDR\n", 1)[1] == px.tobytes(), name
+    r = subprocess.run([batch, "encode", str(src), str(qoi), "--qoi"])  # the mono image cannot be QOI: reported, others written
+    assert r.returncode == 1
+    for name, (px, w, h, ch) in imgs.items():
+        if ch >= 3:
+            assert (qoi / f"{name}.qoi").read_bytes() == po.best().encode(px.reshape(-1), w, h, ch, 1), name
+        else:
+            assert not (qoi / f"{name}.qoi").exists()
