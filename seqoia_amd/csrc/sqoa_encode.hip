@@ -118,15 +118,16 @@ struct RunOut { uint32_t lo, n, big; };
 // Bytes owned by a pixel that repeats its predecessor (seqoia.h:544-561, :640-642): 0xfd on every 512th pixel
 // of a run and on a trailing run, the flush (owned by the run's last pixel) otherwise; flushes longer than one
 // byte only reserve their space (big = q << 8 | last byte).
+template <bool QOI>
 SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long enext, bool end_lane, int lane,
                         unsigned long long le_mask) {
     const bool iseq = (e >> lane) & 1ull;
     const unsigned long long below = ~e & le_mask;
     const uint32_t k = below ? (uint32_t)lane - (63u - (uint32_t)__builtin_clzll(below)) : crun + lane + 1u;
-    const uint32_t r = k & 511u;
+    const uint32_t r = QOI ? k % 62u : k & 511u;   // seqoia.h:411-412
     const bool fd = iseq && (r == 0u || end_lane);
     const bool fl = iseq && !fd && !((enext >> lane) & 1ull);
-    const uint32_t q = ((r - 1u) * 1075u) >> 16;  // (r-1)/61 for r <= 511
+    const uint32_t q = QOI ? 0u : ((r - 1u) * 1075u) >> 16;  // (r-1)/61 for r <= 511; QOI remainders are <= 61
     const uint32_t last = fd ? 0xfdu : 0xc0u | (r - 1u - 61u * q);
     RunOut o;
     o.lo = (fd || (fl && q == 0u)) ? last : 0u;
@@ -138,6 +139,7 @@ SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long 
 struct SwarGroup { uint32_t W0, W1, W2, W3, AH, b0, Nn; };  // bytes 0..3 and 4 of every pixel's literal op (byte i = row i)
 
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
+template <bool QOI>
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
     const uint32_t H = sconst<0x80808080u>(), L = sconst<0x7f7f7f7fu>();
     const uint32_t C08 = sconst<0x08080808u>(), C20 = sconst<0x20202020u>(), C10 = sconst<0x10101010u>();
@@ -165,32 +167,63 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
         const uint32_t DGm = ((DG | H) - C08) ^ ((DG & H) ^ H);                 // vg - 8
         const uint32_t XR = sub8(DR, DGm), XB = sub8(DB, DGm);                  // vg_r + 8, vg_b + 8
         const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
-        const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
-        const uint32_t z0 = nz(DR | DG | DB | DA), z1 = nz(bad), z2 = nz(DA);
-        const uint32_t b0 = z0 >> 7, b1 = z1 >> 7, b2 = z2 >> 7;   // 1 = differs from its predecessor; needs RGB/RGBA; alpha moved
-        // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
-        const uint32_t ne_mask = (z0 - b0) | z0, raw_mask = (z1 - b1) | z1, na_mask = (z2 - b2) | z2;
-        const uint32_t L0 = XG | H;                                  // LUMA byte 0 (seqoia.h:612)
-        const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);          // LUMA byte 1 (seqoia.h:614)
-        const uint32_t L2 = (XA | C60) & na_mask;                    // ALPHA suffix (seqoia.h:617)
-        const uint32_t TG = CFE | b2;                                // RGB / RGBA tag (seqoia.h:622)
         SwarGroup& o = grp[g];
-        // the op's bytes, already chosen between LUMA[+ALPHA] and RGB[A]; zero for repeated pixels
-        o.W0 = ((L0 & ~raw_mask) | (TG & raw_mask)) & ne_mask;
-        o.W1 = ((L1 & ~raw_mask) | (R & raw_mask)) & ne_mask;
-        o.W2 = ((L2 & ~raw_mask) | (G & raw_mask)) & ne_mask;
-        o.W3 = B & raw_mask & ne_mask;
-        o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
-        o.b0 = b0;
-        o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+        if constexpr (!QOI) {
+            const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
+            const uint32_t z0 = nz(DR | DG | DB | DA), z1 = nz(bad), z2 = nz(DA);
+            const uint32_t b0 = z0 >> 7, b1 = z1 >> 7, b2 = z2 >> 7;   // 1 = differs from its predecessor; needs RGB/RGBA; alpha moved
+            // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
+            const uint32_t ne_mask = (z0 - b0) | z0, raw_mask = (z1 - b1) | z1, na_mask = (z2 - b2) | z2;
+            const uint32_t L0 = XG | H;                                  // LUMA byte 0 (seqoia.h:612)
+            const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);          // LUMA byte 1 (seqoia.h:614)
+            const uint32_t L2 = (XA | C60) & na_mask;                    // ALPHA suffix (seqoia.h:617)
+            const uint32_t TG = CFE | b2;                                // RGB / RGBA tag (seqoia.h:622)
+            // the op's bytes, already chosen between LUMA[+ALPHA] and RGB[A]; zero for repeated pixels
+            o.W0 = ((L0 & ~raw_mask) | (TG & raw_mask)) & ne_mask;
+            o.W1 = ((L1 & ~raw_mask) | (R & raw_mask)) & ne_mask;
+            o.W2 = ((L2 & ~raw_mask) | (G & raw_mask)) & ne_mask;
+            o.W3 = B & raw_mask & ne_mask;
+            o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
+            o.b0 = b0;
+            o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+        } else {
+            // QOI-compat ops for a pixel that missed the index (seqoia.h:573-634): alpha moved -> RGBA; else DIFF if
+            // vr, vg, vb in [-2, 1]; else LUMA; else RGB
+            const uint32_t C02 = sconst<0x02020202u>(), MFC = sconst<0xfcfcfcfcu>(), C40 = sconst<0x40404040u>(), ONE = sconst<0x01010101u>();
+            const uint32_t ER = ((DR & L) + C02) ^ (DR & H), EG = ((DG & L) + C02) ^ (DG & H), EB = ((DB & L) + C02) ^ (DB & H);  // v + 2
+            const uint32_t z0 = nz(DR | DG | DB | DA), z2 = nz(DA);
+            const uint32_t zd = nz((ER | EG | EB) & MFC);                  // 0x80: DIFF does not fit
+            const uint32_t zl = nz(((XR | XB) & MF0) | (XG & MC0));        // 0x80: LUMA does not fit
+            const uint32_t b0 = z0 >> 7;
+            const uint32_t ne_mask = (z0 - b0) | z0;
+            const uint32_t na_mask = (z2 - (z2 >> 7)) | z2;                // RGBA
+            const uint32_t nd_mask = (zd - (zd >> 7)) | zd, nl_mask = (zl - (zl >> 7)) | zl;
+            const uint32_t df_mask = ~na_mask & ~nd_mask;                  // DIFF
+            const uint32_t lu_mask = ~na_mask & nd_mask & ~nl_mask;        // LUMA
+            const uint32_t rw_mask = na_mask | (nd_mask & nl_mask);        // RGB or RGBA: r g b follow the tag
+            // seqoia.h:599; the shifts run across byte lanes, so every field is masked to its own two bits
+            const uint32_t DIFFB = C40 | ((ER << 4) & sconst<0x30303030u>()) | ((EG << 2) & sconst<0x0c0c0c0cu>()) | (EB & sconst<0x03030303u>());
+            const uint32_t L0 = XG | H, L1 = ((XR << 4) & MF0) | (XB & M0F);
+            o.W0 = ((DIFFB & df_mask) | (L0 & lu_mask) | (CFE & rw_mask) | (ONE & na_mask)) & ne_mask;  // 0xfe | 1 = 0xff
+            o.W1 = ((L1 & lu_mask) | (R & rw_mask)) & ne_mask;
+            o.W2 = G & rw_mask & ne_mask;
+            o.W3 = B & rw_mask & ne_mask;
+            o.AH = A & na_mask;
+            o.b0 = b0;
+            // bytes: DIFF 1, LUMA 2, RGB 4, RGBA 5
+            o.Nn = (((ONE & df_mask) | ((ONE << 1) & lu_mask) | ((ONE << 2) & rw_mask)) + (ONE & na_mask)) & (ne_mask & (ONE * 7u));
+        }
+        const uint32_t b0 = o.b0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) E[4 * g + i] = __ballot((b0 & (1u << (8 * i))) == 0u);
     }
 }
 
 // Phase B: run bytes, byte offsets (two DPP prefix sums per four rows) and staging into LDS.
+template <bool QOI>
 SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
-                            uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask) {
+                            uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask, uint32_t* tabw,
+                            unsigned long long* smask) {
     uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
     cr[0] = c_in;
 #pragma unroll
@@ -200,6 +233,26 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
     for (int g = 0; g < ENC_S / 4; ++g) {
         const SwarGroup& G = grp[g];
         uint32_t Nn = G.Nn, W0 = G.W0;
+        uint32_t hitv[4] = {0, 0, 0, 0};  // QOI: 0x100 | slot where the pixel hits the colour index
+        if constexpr (QOI) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // index probe (seqoia.h:563-572), the 64 pixels of a row at once, rows in order
+                const uint32_t px = cur[4 * g + i];
+                const bool ne = (G.b0 >> (8 * i)) & 1u;
+                const uint32_t h = qoi_hash(px);
+                uint32_t cand = tabw[h];  // slot as the previous rows left it
+                if (ne) __hip_atomic_fetch_or(&smask[h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const unsigned long long m = __hip_atomic_load(&smask[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const unsigned long long lower = m & (le_mask >> 1);  // earlier lanes of this row on my slot
+                const int from = lower ? 63 - __builtin_clzll(lower) : lane;
+                const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
+                if (lower) cand = near;
+                if (ne && (m & ~le_mask) == 0ull) { tabw[h] = px; smask[h] = 0; }  // last writer of the slot in this row
+                const bool hit = ne && cand == px;
+                hitv[i] = hit ? 0x100u | h : 0u;
+                if (hit) Nn = (Nn & ~(0xffu << (8 * i))) | 1u << (8 * i);  // QOI_OP_INDEX: one byte
+            }
+        }
         // pixels that repeat their predecessor: run bookkeeping per row, skipped for rows without any;
         // their (single) run byte joins byte plane 0, which is zero there
         uint32_t rbig[4] = {0, 0, 0, 0};
@@ -207,7 +260,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
         for (int i = 0; i < 4; ++i) {
             const int s = 4 * g + i;
             const unsigned long long e = E[s];
-            if (e == ~0ull) {
+            if (!QOI && e == ~0ull) {
                 // the whole row continues one run: at most one 0xfd (the lane where k mod 512 == 0) and, on lane 63,
                 // the flush or the trailing 0xfd -- all of it wave-uniform arithmetic
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
@@ -229,7 +282,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             } else if (e != 0ull) {
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
                 const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
-                const RunOut ro = run_row(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
+                const RunOut ro = run_row<QOI>(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
                 W0 |= ro.lo << (8 * i);
                 rbig[i] = ro.big;
                 Nn += ro.n << (8 * i);
@@ -251,7 +304,8 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             const uint32_t n = (Nn >> (8 * i)) & 255u;
             const uint32_t incl = ((i < 2 ? i01 : i23) >> (16 * (i & 1))) & 0xffffu;
             const uint32_t o = rowbase[i] + incl - n;
-            const uint32_t lo = lo4[i], hi = (G.AH >> (8 * i)) & 255u;
+            uint32_t lo = lo4[i], hi = (G.AH >> (8 * i)) & 255u;
+            if (QOI && hitv[i]) { lo = hitv[i] & 63u; hi = 0; }
             const uint32_t sh = (o & 3u) * 8u;
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
             uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
@@ -378,11 +432,11 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
         // ---- pre-pass: equality masks (from the SWAR classification on the fast path), local run aggregate ----
         unsigned long long E[ENC_S];
-        const bool swar = !QOI && !mono && base + ENC_SUB <= N;
+        const bool swar = !mono && base + ENC_SUB <= N;
         SwarGroup grp[ENC_S / 4];
         // a sub-tile that is one solid run (flat areas of icons / screenshots) needs no per-pixel work at all
         bool flat = false;
-        if (swar) {
+        if (swar && !QOI) {
             uint32_t dif = 0;
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
@@ -391,7 +445,7 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         if (flat) {
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) E[s] = ~0ull;
-        } else if (swar) swar_classify(cur, pb, grp, E);
+        } else if (swar) swar_classify<QOI>(cur, pb, grp, E);
         else {
             uint32_t carry = pb;
 #pragma unroll
@@ -484,7 +538,7 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
             }
             sbase = nbytes;
         } else if (swar) {
-            sbase = swar_emit(cur, grp, E, c_in, pa, has_after, stage, lane, le_mask);
+            sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, stage, lane, le_mask, tabw, smask);
         } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t carry = pb;
