@@ -264,3 +264,26 @@ def test_plans_replay_from_a_hip_graph(sq, orc):
             assert bytes(enc.out[k, : int(r["len"][k])].cpu().numpy()) == want, (seed, k)
     dec.close()
     enc.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_large_single_image(sq, orc, mode):
+    """One screenshot-sized image (3840x2160, the largest class of SURVEY.md Appendix C's suite table): 16 200
+    sub-tiles through one workgroup's chains, output positions beyond 2^24, both wire formats, encode and decode."""
+    import torch
+
+    w, h = 3840, 2160
+    px = torch.empty((1, h, w, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=3, img0=5)
+    enc = sq.EncodePlan(px, qoi_compat=mode)
+    enc.launch()
+    res = enc.results()
+    assert res["status"][0] == 0
+    want = orc.best().encode(orc.synth(w, h, 4, "mixed", 3, 5), w, h, 4, mode)
+    assert enc.streams()[0] == want
+    dec = sq.DecodePlan(enc.out, res["len"], w, h, 4)
+    dec.launch()
+    assert dec.results()["status"][0] == 0
+    assert torch.equal(dec.out, px)
+    dec.close()
+    enc.close()
