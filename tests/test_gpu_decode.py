@@ -287,3 +287,44 @@ def test_large_single_image(sq, orc, mode):
     assert torch.equal(dec.out, px)
     dec.close()
     enc.close()
+
+
+def test_batch_decode_random_bodies_match_oracle(sq, orc):
+    """Differential fuzz with NO structure: random bytes behind a valid header (successor of sqoafuzz.c:20-32 on the
+    batch path).  SQOA bodies hit REF / ALPHA / run-as-op paths at random; QOI bodies hit INDEX on an empty table;
+    mono headers go to the 128-entry index.  The GPU must agree with the reference on every stream, including
+    which ones are refused (REF pointing before the start, seqoia.h:733-736)."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(2025)
+    by_geom = {}
+    for k in range(384):
+        w, h = [(40, 30), (64, 64), (97, 13)][k % 3]
+        hdr_ch = [4, 3, 4, 1, 2, 5, 6][k % 7]
+        magic = b"qoif" if k % 4 == 1 else b"Sqoa"
+        start = b"" if (magic == b"qoif" or k % 16 == 3) else b"\x31"  # k%16==3: "Sqoa" without start byte = QOI mode
+        n = int(rng.integers(1, 1400))
+        body = rng.integers(0, 256, size=n, dtype=np.uint8)
+        if k % 5 == 0:  # bias towards op bytes that keep the stream going
+            body = np.where(rng.random(n) < 0.5, rng.integers(0x80, 0x100, size=n), body).astype(np.uint8)
+        s = magic + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([hdr_ch, 0]) + start + body.tobytes() + bytes(7) + b"\x01"
+        by_geom.setdefault((w, h), []).append(s)
+    for (w, h), streams in by_geom.items():
+        for oc in (4, 3):
+            wants = [o.decode(s, oc)[0] for s in streams]
+            slot = max(len(s) for s in streams) + 32
+            buf = np.zeros((len(streams), slot), dtype=np.uint8)
+            for i, s in enumerate(streams):
+                buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+            dec = sq.DecodePlan(torch.from_numpy(buf).cuda(), [len(s) for s in streams], w, h, oc)
+            dec.launch()
+            res = dec.results()
+            out = dec.out.cpu().numpy()
+            for i, want in enumerate(wants):
+                if want is None:
+                    assert res["status"][i] != 0, (w, h, oc, i)
+                else:
+                    assert res["status"][i] == 0, (w, h, oc, i, int(res["status"][i]))
+                    assert out[i].tobytes() == want.tobytes(), (w, h, oc, i)
+            dec.close()
