@@ -644,7 +644,10 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
     if (n <= 0) return hipSuccess;
     // 8 waves per image: the kernel is VALU-issue bound (most of its ops are 8-byte VOP3/SDWA/DPP encodings,
     // which issue at half the rate of 4-byte VOP2 on gfx950: tools/ubench/valu_rate.hip), more resident waves help
-    constexpr int W = 8;
+#ifndef SQOA_ENC_W
+#define SQOA_ENC_W 8
+#endif
+    constexpr int W = SQOA_ENC_W;
     if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
     return hipGetLastError();
