@@ -24,6 +24,7 @@ namespace sqoa {
 constexpr int ENC_S = 8;               // steps per sub-tile
 constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
 constexpr int ENC_STG = 2816;          // staging bytes per wave: 5 B/px * 512 + 9 + spill, multiple of 16
+constexpr int ENC_SINK = 512;          // behind it: one 8-byte sink per lane, where pixels that emit nothing OR their zeros
 constexpr uint32_t SPIN_MAX = 1u << 22;
 
 struct EncState {
@@ -297,6 +298,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
         // back from byte planes to one dword per row: a 4x4 byte transpose (8 v_perm_b32, same selectors as the way in)
         const uint32_t w01 = __builtin_amdgcn_perm(G.W1, W0, 0x05010400u), w23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x05010400u);
         const uint32_t u01 = __builtin_amdgcn_perm(G.W1, W0, 0x07030602u), u23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x07030602u);
+        uint32_t obig[4];
         const uint32_t lo4[4] = {__builtin_amdgcn_perm(w23, w01, 0x05040100u), __builtin_amdgcn_perm(w23, w01, 0x07060302u),
                                  __builtin_amdgcn_perm(u23, u01, 0x05040100u), __builtin_amdgcn_perm(u23, u01, 0x07060302u)};
 #pragma unroll
@@ -308,23 +310,22 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             if (QOI && hitv[i]) { lo = hitv[i] & 63u; hi = 0; }
             const uint32_t sh = (o & 3u) * 8u;
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
-            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
-            if (E[4 * g + i] == 0ull) {  // every pixel of the row emits a literal op
-                __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            } else {
-                if (n) {
-                    __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-                if (__ballot(rbig[i] != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
-                    if (rbig[i]) {
-                        const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
-                        for (uint32_t t = 0; t <= q; ++t) {
-                            const uint32_t ob = o + t;
-                            __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        }
+            // pixels that emit nothing send their zero to a private sink instead of being masked off: no exec juggling,
+            // and no 64 lanes OR-ing the same dword
+            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (n ? (o & ~3u) : (uint32_t)ENC_STG + 8u * lane));
+            __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            obig[i] = o;
+        }
+        if (__ballot((rbig[0] | rbig[1] | rbig[2] | rbig[3]) != 0u) != 0ull) {  // run remainder >= 62: q x 0xfc, then the last byte (rare)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (rbig[i]) {
+                    const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
+                    for (uint32_t t = 0; t <= q; ++t) {
+                        const uint32_t ob = obig[i] + t;
+                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                 }
             }
@@ -337,7 +338,7 @@ template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
                                                         sqoa_hip_result* __restrict__ results) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG + ENC_SINK];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
     // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
     uint8_t* stage = s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; }
-    for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16u; i < (uint32_t)(ENC_STG + ENC_SINK); i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     if (w == 0 && (uint32_t)lane < hdr_len) {  // seqoia.h:497-514
