@@ -266,7 +266,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         uint32_t val[DEC_LB];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
         uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13 | abs flags << 30
         Xf T{0u, 0u};
-        uint32_t cl = 0;
+        uint32_t cl = 0, iters = DEC_LB, longest = 0;
         bool ref_seen = false;
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             if (__ballot(act) == 0ull) {
 #pragma unroll
                 for (int r = i; r < DEC_LB; ++r) { val[r] = 0; meta[r] = 0; }
+                iters = i;
                 break;
             }
             if (__ballot(act && b0 < 0x60u) != 0ull) { ref_seen = true; break; }  // SQOA_OP_REF: serial path
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             val[i] = T.v;
             meta[i] = cl | (cnt & on) << 13 | (T.abs & 1u) << 30 | (T.abs >> 31) << 31;
             cl += cnt & on;
+            longest |= cnt & on;  // > 1 iff some op of mine is a run
             pos += (len + (has_sfx ? 1u : 0u)) & on;
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
@@ -328,13 +330,24 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         if (pos_in < N) {
             const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
+            const bool plain = oc == 4 && pos_in + ctot <= N && __ballot(longest > 1u) == 0ull;
+            if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
+#pragma unroll
+                for (int i = 0; i < DEC_LB; ++i) {
+                    if ((uint32_t)i >= iters) break;
+                    const uint32_t m = meta[i];
+                    const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
+                    const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
+                    if (m & (0x3ffu << 13)) ((gptr32)out)[lane_p + (m & 0x1fffu)] = v;
+                }
+            } else {
             auto store_ops = [&](auto oc_tag) {
                 constexpr int OC = decltype(oc_tag)::value;
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
+                    if ((uint32_t)i >= iters) break;
                     const uint32_t m = meta[i];
                     const uint32_t cnt = (m >> 13) & 0x3ffu;
-                    if (__ballot(cnt != 0u) == 0ull) break;
                     const uint32_t P = lane_p + (m & 0x1fffu);
                     const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
                     const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
@@ -355,6 +368,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             };
             if (oc == 4) store_ops(std::integral_constant<int, 4>{});
             else store_ops(std::integral_constant<int, 3>{});
+            }
         }
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
