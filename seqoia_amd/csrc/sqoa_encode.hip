@@ -322,6 +322,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             for (int i = 0; i < 4; ++i) {
                 if (rbig[i]) {
                     const uint32_t q = rbig[i] >> 8, last = rbig[i] & 255u;
+#pragma nounroll
                     for (uint32_t t = 0; t <= q; ++t) {
                         const uint32_t ob = obig[i] + t;
                         __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
