@@ -17,6 +17,8 @@
 //
 // No MFMA: there is no contraction here.  The bound is HBM (4 B/px read,
 // ~2.6 B/px written on the headline batch).
+#include <type_traits>
+
 #include "sqoa_common.h"
 
 namespace sqoa {
@@ -418,12 +420,12 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         }
     };
 
-    uint32_t j = w;
-    if (j < nsub) load_sub(j, cur, cur_pb, cur_pa);
-
-    for (; j < nsub; j += W) {
+    // One sub-tile.  SW (compile time) = the SWAR path: colour image, sub-tile fully inside the image.  The loop over the
+    // full sub-tiles of a colour image is instantiated with SW = true only, so the generic one-row-per-step code (mono
+    // images, the partial sub-tile at the end of an image) stays out of the hot loop.
+    auto body = [&](auto sw_tag, uint32_t j, bool more) {
+        constexpr bool SW = decltype(sw_tag)::value;
         uint32_t nxt[ENC_S], nxt_pb = 0, nxt_pa = 0;
-        const bool more = j + W < nsub;
         if (more) load_sub(j + W, nxt, nxt_pb, nxt_pa);
 
         const uint32_t base = j * ENC_SUB;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
 
         // ---- pre-pass: equality masks (from the SWAR classification on the fast path), local run aggregate ----
         unsigned long long E[ENC_S];
-        const bool swar = !mono && base + ENC_SUB <= N;
+        constexpr bool swar = SW;
         SwarGroup grp[ENC_S / 4];
         // a sub-tile that is one solid run (flat areas of icons / screenshots) needs no per-pixel work at all
         bool flat = false;
@@ -635,6 +637,21 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
             cur_pb = nxt_pb;
             cur_pa = nxt_pa;
         }
+    };
+
+    const uint32_t nfull = N / ENC_SUB;  // sub-tiles that lie fully inside the image
+    if (!mono) {
+        uint32_t j = w;
+        if (j < nfull) load_sub(j, cur, cur_pb, cur_pa);
+        for (; j < nfull; j += W) body(std::true_type{}, j, j + W < nfull);
+        if (nsub > nfull && nfull % W == (uint32_t)w) {  // the image's partial last sub-tile
+            load_sub(nfull, cur, cur_pb, cur_pa);
+            body(std::false_type{}, nfull, false);
+        }
+    } else {
+        uint32_t j = w;
+        if (j < nsub) load_sub(j, cur, cur_pb, cur_pa);
+        for (; j < nsub; j += W) body(std::false_type{}, j, j + W < nsub);
     }
     if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);
 }
