@@ -217,10 +217,10 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         }
     };
 
-    uint32_t c = w;
-    if (c < nchunks) load_chunk(c, stg);
-
-    for (; c < nchunks; c += W) {
+    // One chunk.  IN (compile time) = interior chunk: every byte lies inside the chunk area and a successor exists, so the
+    // liveness tests and the end-of-stream handling drop out of the hot loop.  Returns false when the image is handed over.
+    auto body = [&](auto in_tag, uint32_t c) -> bool {
+        constexpr bool IN = decltype(in_tag)::value;
         // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
 #pragma unroll
         for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
         const uint8_t* cb = reinterpret_cast<const uint8_t*>(lds) + (gs & 3u);
         const uint8_t* lb = cb + DEC_LB * lane;                // this lane's 8 bytes
-        const bool last_chunk = c == nchunks - 1;
+        const bool last_chunk = IN ? false : c == nchunks - 1;
         // how many of my bytes lie inside the chunk area (op starts beyond it do not exist, seqoia.h:726)
         const uint32_t my0 = gs + DEC_LB * lane;
-        const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)DEC_LB ? (uint32_t)DEC_LB : chunks_len - my0);
+        const uint32_t nlive = IN ? (uint32_t)DEC_LB : my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)DEC_LB ? (uint32_t)DEC_LB : chunks_len - my0);
 
         // ---- 1. parse: each lane composes the transition functions of its 8 bytes, one wave scan ----
         uint32_t qd[DEC_LB / 4];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
         if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
-        if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) break;
+        if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) return false;
         if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
 
         // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         }
         if (ref_seen) {
             if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
-            break;
+            return false;
         }
 
         // ---- 3. wave scans: pixel positions and pixel transforms of the lanes below ------------
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
         uint32_t pos_in = 0, px_in = kPxInit;
         if (c > 0) {
-            if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) break;
-            if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) break;
+            if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) return false;
+            if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) return false;
         }
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
@@ -377,7 +377,15 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             }
             if (lane == 0) res->len = (int)(N * (uint32_t)oc);
         }
-    }
+        return true;
+    };
+
+    uint32_t c = w;
+    if (c < nchunks) load_chunk(c, stg);
+    const uint32_t nint = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
+    bool go = true;
+    for (; go && c < nint; c += W) go = body(std::true_type{}, c);
+    for (; go && c < nchunks; c += W) go = body(std::false_type{}, c);
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 }
 
