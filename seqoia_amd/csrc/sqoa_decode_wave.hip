@@ -267,7 +267,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13 | abs flags << 30
         Xf T{0u, 0u};
         uint32_t cl = 0, iters = DEC_LB, longest = 0;
-        bool ref_seen = false;
+        bool ref_lane = false;
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
             // op byte, <= 4 data bytes, possible ALPHA suffix
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
                 iters = i;
                 break;
             }
-            if (__ballot(act && b0 < 0x60u) != 0ull) { ref_seen = true; break; }  // SQOA_OP_REF: serial path
+            ref_lane |= act && b0 < 0x60u;  // SQOA_OP_REF: checked once after the walk (what follows it in this lane is discarded)
             const uint32_t b1 = ((uint32_t)q >> 8) & 0xffu;
             const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
             const uint32_t sb = (uint32_t)(q >> (8u * len)) & 0xffu;  // byte after the op (seqoia.h:777-783)
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             pos += (len + (has_sfx ? 1u : 0u)) & on;
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
-        if (ref_seen) {
+        if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
             if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
             return false;
         }
