@@ -264,7 +264,8 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u);
         bool sfx_ok = lst != ST_N;  // may the byte at `pos` be an ALPHA suffix of the op before it?
         uint32_t val[DEC_LB];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
-        uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13 | abs flags << 30
+        uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13
+        uint32_t amask[DEC_LB]; // byte mask of the channels of val[] that are absolute
         Xf T{0u, 0u};
         uint32_t cl = 0, iters = DEC_LB, longest = 0;
         bool ref_lane = false;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             const bool act = pos < nlive;
             if (__ballot(act) == 0ull) {
 #pragma unroll
-                for (int r = i; r < DEC_LB; ++r) { val[r] = 0; meta[r] = 0; }
+                for (int r = i; r < DEC_LB; ++r) { val[r] = 0; meta[r] = 0; amask[r] = 0; }
                 iters = i;
                 break;
             }
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             const uint32_t on = act ? 0xffffffffu : 0u;  // lanes that have run out of ops apply the identity
             T = xf_then(T, Xf{((d8 & ~setm) | (base & setm)) & on, setm & on});
             val[i] = T.v;
-            meta[i] = cl | (cnt & on) << 13 | (T.abs & 1u) << 30 | (T.abs >> 31) << 31;
+            meta[i] = cl | (cnt & on) << 13;
+            amask[i] = T.abs;
             cl += cnt & on;
             longest |= cnt & on;  // > 1 iff some op of mine is a run
             pos += (len + (has_sfx ? 1u : 0u)) & on;
@@ -335,10 +337,9 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
-                    const uint32_t m = meta[i];
-                    const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
+                    const uint32_t m = meta[i], am = amask[i];
                     const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
-                    if (m & (0x3ffu << 13)) ((gptr32)out)[lane_p + (m & 0x1fffu)] = v;
+                    if (m >> 13) ((gptr32)out)[lane_p + (m & 0x1fffu)] = v;
                 }
             } else {
             auto store_ops = [&](auto oc_tag) {
@@ -347,9 +348,9 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
                     const uint32_t m = meta[i];
-                    const uint32_t cnt = (m >> 13) & 0x3ffu;
+                    const uint32_t cnt = m >> 13;
                     const uint32_t P = lane_p + (m & 0x1fffu);
-                    const uint32_t am = ((m >> 30) & 1u ? 0x00ffffffu : 0u) | (m >> 31 ? 0xff000000u : 0u);
+                    const uint32_t am = amask[i];
                     const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
                     if (cnt == 1u && P < N) {
                         if (OC == 4) ((gptr32)out)[P] = v;
