@@ -113,8 +113,9 @@ SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int 
 // the other channels are deltas (mod 256) still to be added to whatever pixel enters.
 struct Xf { uint32_t v, abs; };
 // first `a`, then `b`
-SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{(add8(a.v, b.v) & ~b.abs) | (b.v & b.abs), a.abs | b.abs}; }
-SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return (add8(px, t.v) & ~t.abs) | (t.v & t.abs); }
+// (b.v holds the value itself in b's absolute channels and a delta elsewhere, so masking a's side first is enough)
+SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{add8(a.v & ~b.abs, b.v), a.abs | b.abs}; }
+SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return add8(px & ~t.abs, t.v); }
 
 template <int CTRL, int ROWMASK>
 SQOA_DEV Xf xf_scan_step(Xf T) {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
                     const uint32_t m = meta[i], am = amask[i];
-                    const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
+                    const uint32_t v = add8(lane_px & ~am, val[i]);
                     if (m >> 13) ((gptr32)out)[lane_p + (m & 0x1fffu)] = v;
                 }
             } else {
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
                     const uint32_t cnt = m >> 13;
                     const uint32_t P = lane_p + (m & 0x1fffu);
                     const uint32_t am = amask[i];
-                    const uint32_t v = (add8(lane_px, val[i]) & ~am) | (val[i] & am);
+                    const uint32_t v = add8(lane_px & ~am, val[i]);
                     if (cnt == 1u && P < N) {
                         if (OC == 4) ((gptr32)out)[P] = v;
                         else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
