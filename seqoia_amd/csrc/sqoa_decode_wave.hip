@@ -6,17 +6,19 @@
 // exact serial kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
 //
 // Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W, and
-// inside a chunk every lane owns DEC_LB consecutive stream bytes):
-//   1. parse: every byte gets a transition function over the 7 parser states
+// inside a chunk every lane owns DEC_LB = 8 consecutive stream bytes):
+//   1. parse: every byte has a transition function over the 7 parser states
 //      {A: op boundary after an op, N: op boundary where an ALPHA suffix is not allowed,
-//       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes, composition is two
-//      v_perm_b32, so a 64-lane inclusive scan costs 6 DPP steps.  The chunk's total function is
-//      usually constant (the byte stream re-synchronises), so the exit state is published before
-//      the entry state is even known: the chain does not serialise.
-//   2. ops: lanes that sit on an op start decode it from an unaligned 8-byte LDS read (op bytes +
-//      possible ALPHA suffix).  Pixel counts and channel deltas are prefix-summed with DPP;
-//      absolute ops (RGB/RGBA) re-base the sums through __ballot + ds_bpermute.
-//   3. (pixel position, pixel value) entering the chunk arrive through the LDS chain; literal ops
+//       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes (table in LDS), composition is
+//      two v_perm_b32.  A lane composes its 8 bytes, one 6-step DPP scan composes across lanes.  The
+//      chunk's total function is usually constant (the byte stream re-synchronises), so the exit state
+//      is published before the entry state is even known: the parse chain does not serialise.
+//   2. walk: knowing the state in front of its first byte, a lane decodes its own <= 8 ops in order,
+//      each from 8 bytes of LDS (op byte, <= 4 data bytes, possible ALPHA suffix), branch-free.  A pixel
+//      transform is (v, abs): per-channel value, absolute or still a delta mod 256; the lane keeps the
+//      transform after each op and its pixel counts.
+//   3. scans: one DPP prefix sum of the lanes' pixel counts, one DPP scan composing the lanes' transforms.
+//   4. (pixel position, pixel value) entering the chunk arrive through the LDS chain; literal ops
 //      store their pixel directly, runs are expanded cooperatively by the whole wave.
 #include <type_traits>
 

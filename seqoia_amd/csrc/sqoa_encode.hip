@@ -3,16 +3,15 @@
 // Replaces the per-pixel loop of the reference encoder (seqoia.h:530-638) and
 // its tail (seqoia.h:640-649).  Dataflow, per image:
 //
-//   * the image is cut into sub-tiles of 512 pixels; sub-tile j is owned by
-//     wave (j mod W) of the image's workgroup, which walks j, j+W, j+2W, ...
-//   * inside a sub-tile a wave runs 8 steps of 64 pixels, one pixel per lane:
-//     coalesced 256-byte row loads, previous pixel by DPP wave_shr, run
-//     detection by __ballot, op bytes by straight-line integer code, byte
-//     offsets by a 6-step DPP prefix sum, and variable-length compaction by
-//     OR-ing each lane's (<= 9) bytes into a wave-private LDS staging buffer;
-//   * the only state that crosses sub-tiles is (run length, output position
-//     [, colour index]); it travels wave -> wave through tagged 8-byte LDS
-//     words (a decoupled look-back chain inside the workgroup, no barrier);
+//   * the image is cut into sub-tiles of 512 pixels = 8 rows of 64; sub-tile j is owned by wave (j mod W) of the
+//     image's workgroup, which walks j, j+W, j+2W, ... with the next sub-tile's loads in flight;
+//   * colour images take the SWAR path: the op decision (LUMA / ALPHA / RGB[A], DIFF in QOI mode) is made for the
+//     same lane of FOUR rows at once, bytewise inside dwords (swar_classify); per row follow run bookkeeping from
+//     the __ballot equality masks, byte offsets from DPP prefix sums, and variable-length compaction by OR-ing
+//     each lane's (<= 9) bytes into a wave-private LDS staging buffer (swar_emit).  Mono images and the partial
+//     sub-tile at the end of an image take the one-row-per-step path (literal_op);
+//   * the only state that crosses sub-tiles is (run length, output position [, colour index]); it travels
+//     wave -> wave through tagged 8-byte LDS words (a decoupled look-back chain inside the workgroup, no barrier);
 //   * finished bytes leave LDS as 16-byte global stores, edges as byte stores.
 //
 // No MFMA: there is no contraction here.  The bound is HBM (4 B/px read,
