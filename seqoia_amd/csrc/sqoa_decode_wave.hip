@@ -275,9 +275,12 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
             // op byte, <= 4 data bytes, possible ALPHA suffix
-            unsigned long long q = lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB));
-            uint32_t b0 = (uint32_t)q & 0xffu;
-            if (sfx_ok && (b0 - 0x60u) < 0x20u) { pos += 1u; q >>= 8; b0 = (uint32_t)q & 0xffu; }  // only possible for i == 0
+            if (i == 0) {  // an ALPHA byte at my first op boundary belongs to the op in front of it: step over it
+                const uint32_t f0 = (lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB))) & 0xffu;
+                if (sfx_ok && (f0 - 0x60u) < 0x20u) pos += 1u;
+            }
+            const unsigned long long q = lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB));
+            const uint32_t b0 = (uint32_t)q & 0xffu;
             const bool act = pos < nlive;
             if (__ballot(act) == 0ull) {
 #pragma unroll
@@ -299,15 +302,21 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             const uint32_t dl = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
             const uint32_t d8 = (is_luma ? dl : 0u) | da << 24;
             // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775); everything else is one pixel
-            const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+            uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+            // A RUN right behind a literal op repeats exactly the pixel this op produces (pixel pairs, short repeats):
+            // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
+            const uint32_t adv = len + (has_sfx ? 1u : 0u);
+            const uint32_t nb = (uint32_t)(q >> (8u * adv)) & 0xffu, nn = (uint32_t)(q >> (8u * adv + 8u)) & 0xffu;
+            const bool fuse = (is_abs || is_luma) && (nb - 0xc0u) < 0x3eu && (nn - 0x60u) >= 0x20u && pos + adv < nlive;
+            cnt += fuse ? (nb == 0xfdu ? 512u : (nb & 0x3fu) + 1u) : 0u;
             const uint32_t on = act ? 0xffffffffu : 0u;  // lanes that have run out of ops apply the identity
             T = xf_then(T, Xf{((d8 & ~setm) | (base & setm)) & on, setm & on});
             val[i] = T.v;
             meta[i] = cl | (cnt & on) << 13;
             amask[i] = T.abs;
             cl += cnt & on;
-            longest |= cnt & on;  // > 1 iff some op of mine is a run
-            pos += (len + (has_sfx ? 1u : 0u)) & on;
+            longest = longest > (cnt & on) ? longest : (cnt & on);
+            pos += (adv + (fuse ? 1u : 0u)) & on;
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
@@ -335,14 +344,16 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
         if (pos_in < N) {
             const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
-            const bool plain = oc == 4 && pos_in + ctot <= N && __ballot(longest > 1u) == 0ull;
+            const bool plain = oc == 4 && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
             if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
                     const uint32_t m = meta[i], am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
-                    if (m >> 13) ((gptr32)out)[lane_p + (m & 0x1fffu)] = v;
+                    gptr32 o = (gptr32)out + lane_p + (m & 0x1fffu);
+                    if (m >> 13) o[0] = v;
+                    if (m >> 14) o[1] = v;  // cnt == 2: a literal op and the one-pixel run behind it
                 }
             } else {
             auto store_ops = [&](auto oc_tag) {
@@ -355,11 +366,15 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
                     const uint32_t P = lane_p + (m & 0x1fffu);
                     const uint32_t am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
-                    if (cnt == 1u && P < N) {
+                    if (cnt >= 1u && cnt <= 2u && P < N) {
                         if (OC == 4) ((gptr32)out)[P] = v;
                         else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
                     }
-                    unsigned long long runs = __ballot(cnt > 1u && P < N);
+                    if (cnt == 2u && P + 1u < N) {
+                        if (OC == 4) ((gptr32)out)[P + 1u] = v;
+                        else { gptr8 o = out + (size_t)(P + 1u) * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                    }
+                    unsigned long long runs = __ballot(cnt > 2u && P < N);
                     while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
                         const int l = __builtin_ctzll(runs);
                         runs &= runs - 1ull;
