@@ -303,12 +303,14 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
             const uint32_t d8 = (is_luma ? dl : 0u) | da << 24;
             // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775); everything else is one pixel
             uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
-            // A RUN right behind a literal op repeats exactly the pixel this op produces (pixel pairs, short repeats):
+            // A RUN right behind an op repeats exactly the pixel this op produces (pixel pairs, short repeats, split runs):
             // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
             const uint32_t adv = len + (has_sfx ? 1u : 0u);
             const uint32_t nb = (uint32_t)(q >> (8u * adv)) & 0xffu, nn = (uint32_t)(q >> (8u * adv + 8u)) & 0xffu;
-            const bool fuse = (is_abs || is_luma) && (nb - 0xc0u) < 0x3eu && (nn - 0x60u) >= 0x20u && pos + adv < nlive;
-            cnt += fuse ? (nb == 0xfdu ? 512u : (nb & 0x3fu) + 1u) : 0u;
+            const uint32_t extra = nb == 0xfdu ? 512u : (nb & 0x3fu) + 1u;
+            // (a run behind a run also repeats the same pixel; the 10-bit count field is the only limit)
+            const bool fuse = (nb - 0xc0u) < 0x3eu && (nn - 0x60u) >= 0x20u && pos + adv < nlive && cnt + extra < 1024u;
+            cnt += fuse ? extra : 0u;
             const uint32_t on = act ? 0xffffffffu : 0u;  // lanes that have run out of ops apply the identity
             T = xf_then(T, Xf{((d8 & ~setm) | (base & setm)) & on, setm & on});
             val[i] = T.v;
