@@ -24,6 +24,12 @@
 
 #include "sqoa_common.h"
 
+#ifndef SQOA_PRIO_T1  // progress (in 64ths of the image) at which a workgroup drops to wave priority 2, 1, 0
+#define SQOA_PRIO_T1 40
+#define SQOA_PRIO_T2 54
+#define SQOA_PRIO_T3 61
+#endif
+
 namespace sqoa {
 
 #ifndef SQOA_DEC_LB
@@ -137,8 +143,13 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 }
 
 
+// 64 VGPRs = 8 waves per SIMD = four 8-wave streams per CU (see sqoa_encode.hip)
+#ifndef SQOA_DEC_WPE
+#define SQOA_DEC_WPE 8
+#endif
+#define SQOA_DEC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SQOA_DEC_WPE, SQOA_DEC_WPE)))
 template <int W>
-__global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
+__global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
@@ -405,7 +416,26 @@ __global__ __launch_bounds__(W * 64) void decode_wave_kernel(const sqoa_hip_job*
     if (c < nchunks) load_chunk(c, stg);
     const uint32_t nint = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
     bool go = true;
+#if !defined(SQOA_DEC_PRIO) || SQOA_DEC_PRIO
+    // Progress-based wave priority: the SIMD arbiter is oldest-first, so of the workgroups sharing a CU the oldest runs
+    // almost at solo speed and the youngest finishes alone on a nearly empty CU.  Lowering a stream's priority as it
+    // advances keeps co-resident streams within a quarter of each other.
+    const uint32_t thr1 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T1 >> 6), thr2 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T2 >> 6),
+                   thr3 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T3 >> 6);
+    uint32_t thr = thr1, q = 0;
+    __builtin_amdgcn_s_setprio(3);
+    for (; go && c < nint; c += W) {
+        if (c >= thr) {
+            ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
+            if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        go = body(std::true_type{}, c);
+    }
+#else
     for (; go && c < nint; c += W) go = body(std::true_type{}, c);
+#endif
     for (; go && c < nchunks; c += W) go = body(std::false_type{}, c);
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 }

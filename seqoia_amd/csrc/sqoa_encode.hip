@@ -20,12 +20,19 @@
 
 #include "sqoa_common.h"
 
+#ifndef SQOA_PRIO_T1  // progress (in 64ths of the image) at which a workgroup drops to wave priority 2, 1, 0
+#define SQOA_PRIO_T1 40
+#define SQOA_PRIO_T2 54
+#define SQOA_PRIO_T3 61
+#endif
+
 namespace sqoa {
 
 constexpr int ENC_S = 8;               // steps per sub-tile
 constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
-constexpr int ENC_STG = 2816;          // staging bytes per wave: 5 B/px * 512 + 9 + spill, multiple of 16
-constexpr int ENC_SINK = 512;          // behind it: one 8-byte sink per lane, where pixels that emit nothing OR their zeros
+constexpr int ENC_STG = 2624;          // staging bytes per wave: 5 B/px * 512, + 9 (run flush) + 12 (OR window) + 16 (clear), multiple of 16
+constexpr int ENC_SINK = 272;          // behind it: one dword sink per lane (+1), where pixels that emit nothing OR their zeros
+constexpr int ENC_PRE = ENC_SUB * 4;   // landing buffer of the next sub-tile's pixels (global -> LDS without passing VGPRs)
 constexpr uint32_t SPIN_MAX = 1u << 22;
 
 struct EncState {
@@ -84,6 +91,15 @@ SQOA_DEV void literal_op(uint32_t px, uint32_t pv, bool mono, uint32_t& lo, uint
     hi = (!luma && na) ? px >> 24 : 0u;
     n = (luma ? 2u : 4u) + (na ? 1u : 0u);
 }
+
+// One pixel at a wave-uniform address (any alignment) through the scalar cache: the two aligned dwords that hold its
+// first and last byte (never a byte outside them), shifted together.  Upper bytes beyond `ch` are unspecified.
+typedef const __attribute__((address_space(4))) uint32_t* kcptr32;
+SQOA_DEV uint32_t sload_px(unsigned long long addr, int ch) {
+    const uint32_t lo = *(kcptr32)(addr & ~3ull), hi = *(kcptr32)((addr + (unsigned)ch - 1u) & ~3ull);
+    return (uint32_t)(((unsigned long long)hi << 32 | lo) >> (((uint32_t)addr & 3u) * 8u));
+}
+typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
 SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
@@ -313,7 +329,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
             // pixels that emit nothing send their zero to a private sink instead of being masked off: no exec juggling,
             // and no 64 lanes OR-ing the same dword
-            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (n ? (o & ~3u) : (uint32_t)ENC_STG + 8u * lane));
+            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (n ? (o & ~3u) : (uint32_t)ENC_STG + 4u * lane));
             __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             obig[i] = o;
@@ -336,11 +352,18 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
     return sbase;
 }
 
+// 64 VGPRs = 8 waves per SIMD = four 8-wave images per CU: the 1024 images of the headline batch are all resident at once
+// (at 79 VGPRs a CU held three, and the last quarter of the batch ran on a third of the machine).
+#ifndef SQOA_ENC_WPE
+#define SQOA_ENC_WPE 8
+#endif
+#define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SQOA_ENC_WPE, SQOA_ENC_WPE)))
 template <int W, bool QOI>
-__global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
+__global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
                                                         sqoa_hip_result* __restrict__ results) {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG + ENC_SINK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pre[W][ENC_PRE];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
     // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
@@ -383,39 +406,63 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         dst[lane] = b;
     }
 
+#ifdef SQOA_TRACE  // diagnostic builds only: workgroup start / end time and placement in the unused tail of the slot
+    unsigned long long* trace = (unsigned long long*)((job.dst + job.dst_cap - 32) & ~7ull);
+    if (threadIdx.x == 0) { trace[0] = wall_clock64(); trace[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32; }
+#endif
     EncState st{0};
     const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane
 
-    uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;
-    // Loads of one sub-tile.  The common shapes (sub-tile fully inside the image, 4- or 3-byte pixels) are
-    // straight-line so that all ten loads are in flight together and nothing waits until first use; a
-    // bounds test or a channel switch per load would put an s_waitcnt vmcnt(0) behind every one of them.
-    auto load_sub = [&](uint32_t j, uint32_t (&px)[ENC_S], uint32_t& pb, uint32_t& pa) {
+    uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
+    bool cur_raw3 = false;
+    uint8_t* pre = s_pre[w];
+    // The pixels of a wave's NEXT sub-tile travel global -> LDS directly (global_load_lds_dwordx4, any source alignment:
+    // tools/ubench/lds_dma_align.hip), two instructions per 512 pixels, and are picked up into VGPRs only when the current
+    // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
+    // (64 VGPRs).  The two neighbour pixels are wave-uniform and come through the scalar cache.  Sub-tiles at the image edges,
+    // and 1- / 2-byte pixels, are loaded the plain way and stored to the same buffer as canonical dwords.
+    auto fetch = [&](uint32_t j, uint32_t& pb, uint32_t& pa, bool& raw3) {
         const uint32_t base = j * ENC_SUB;
+        raw3 = false;
         if (base > 0 && base + ENC_SUB < N && ch == 4) {
-            gcptr32 p = (gcptr32)src + base;
-#pragma unroll
-            for (int s = 0; s < ENC_S; ++s) px[s] = p[s * 64 + lane];
-            pb = p[-1];
-            pa = p[ENC_SUB];
+            gcptr8 p = src + (size_t)base * 4;
+            __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
+            pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4);
+            pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4);
         } else if (base > 0 && base + ENC_SUB < N && ch == 3) {
             gcptr8 p = src + (size_t)base * 3;
-#pragma unroll
-            for (int s = 0; s < ENC_S; ++s) {
-                gcptr8 q = p + (s * 64 + lane) * 3;
-                px[s] = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | 0xff000000u;
-            }
-            pb = (uint32_t)p[-3] | (uint32_t)p[-2] << 8 | (uint32_t)p[-1] << 16 | 0xff000000u;
-            gcptr8 q = p + ENC_SUB * 3;
-            pa = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | 0xff000000u;
+            __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
+            if (lane < 32) __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
+            pb = sload_px(job.src + (unsigned long long)base * 3 - 3, 3) | 0xff000000u;
+            pa = sload_px(job.src + (unsigned long long)base * 3 + ENC_SUB * 3, 3) | 0xff000000u;
+            raw3 = true;
         } else {
+            uint32_t px[ENC_S];
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) {
                 const uint32_t idx = base + s * 64 + lane;
                 px[s] = idx < N ? load_px(src, idx, ch) : 0u;
             }
-            pb = base ? load_px(src, base - 1, ch) : kPxInit;
-            pa = base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u;
+            pb = bcast_first(base ? load_px(src, base - 1, ch) : kPxInit);
+            pa = bcast_first(base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u);
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) reinterpret_cast<uint32_t*>(pre)[s * 64 + lane] = px[s];
+        }
+    };
+    auto take = [&](uint32_t (&px)[ENC_S], bool raw3) {
+        // the compiler does not order LDS reads behind LDS-DMA loads by itself
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (raw3) {
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) {
+                uint32_t v;
+                __builtin_memcpy(&v, pre + 3 * (s * 64 + lane), 4);  // unaligned LDS read; the 4th byte is the next pixel's
+                px[s] = v | 0xff000000u;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < ENC_S; ++s) px[s] = reinterpret_cast<const uint32_t*>(pre)[s * 64 + lane];
         }
     };
 
@@ -424,12 +471,15 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
     auto body = [&](auto sw_tag, uint32_t j, bool more) {
         constexpr bool SW = decltype(sw_tag)::value;
-        uint32_t nxt[ENC_S], nxt_pb = 0, nxt_pa = 0;
-        if (more) load_sub(j + W, nxt, nxt_pb, nxt_pa);
+        uint32_t nxt_pb = 0, nxt_pa = 0;
+        bool nxt_raw3 = false;
+        // cur[] was read from the landing buffer at the end of the previous sub-tile and those reads have long returned
+        // (a flush lies in between); the buffer is free for the next sub-tile's pixels
+        if (more) fetch(j + W, nxt_pb, nxt_pa, nxt_raw3);
 
         const uint32_t base = j * ENC_SUB;
-        const uint32_t pb = bcast_first(cur_pb);
-        const uint32_t pa = bcast_first(cur_pa);
+        const uint32_t pb = cur_pb;
+        const uint32_t pa = cur_pa;
         const bool has_after = base + ENC_SUB < N;
         const bool last_sub = j == nsub - 1;
 
@@ -620,6 +670,13 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
         }
         }
 
+        // this sub-tile's pixels are dead: pick up the next one's before the stores of the flush join the memory queue
+        if (more) {
+            take(cur, nxt_raw3);
+            cur_pb = nxt_pb;
+            cur_pa = nxt_pa;
+        }
+
         // ---- output position from the chain, then drain the staging buffer -------------
         const uint32_t pos = j == 0 ? hdr_len : chain_wait(&s_pos[(j - 1) % W], j, st);
         if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
@@ -628,28 +685,45 @@ __global__ __launch_bounds__(W * 64) void encode_kernel(const sqoa_hip_job* __re
             const uint32_t end = pos + sbase;
             if (lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
             if (lane == 0) results[jid].len = (int)(end + 8u);
-        }
-
-        if (more) {
-#pragma unroll
-            for (int s = 0; s < ENC_S; ++s) cur[s] = nxt[s];
-            cur_pb = nxt_pb;
-            cur_pa = nxt_pa;
+#ifdef SQOA_TRACE
+            if (lane == 0) trace[1] = wall_clock64();
+#endif
         }
     };
 
     const uint32_t nfull = N / ENC_SUB;  // sub-tiles that lie fully inside the image
     if (!mono) {
         uint32_t j = w;
-        if (j < nfull) load_sub(j, cur, cur_pb, cur_pa);
+        if (j < nfull) { fetch(j, cur_pb, cur_pa, cur_raw3); take(cur, cur_raw3); }
+#if !defined(SQOA_ENC_PRIO) || SQOA_ENC_PRIO
+        // Progress-based wave priority.  The SIMD arbiter is oldest-first: of the images sharing a CU the oldest runs at
+        // almost solo speed and the youngest finishes alone on a nearly idle CU (tools/trace_encode.py shows the staircase).
+        // Lowering an image's priority as it advances keeps co-resident images within a quarter of each other, so they
+        // finish together and the CU stays full to the end.
+        const uint32_t thr1 = (uint32_t)((unsigned long long)nfull * SQOA_PRIO_T1 >> 6), thr2 = (uint32_t)((unsigned long long)nfull * SQOA_PRIO_T2 >> 6),
+                       thr3 = (uint32_t)((unsigned long long)nfull * SQOA_PRIO_T3 >> 6);
+        uint32_t thr = thr1, q = 0;
+        __builtin_amdgcn_s_setprio(3);
+        for (; j < nfull; j += W) {
+            if (j >= thr) {
+                ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
+                if (q == 1) __builtin_amdgcn_s_setprio(2);
+                else if (q == 2) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+            body(std::true_type{}, j, j + W < nfull);
+        }
+#else
         for (; j < nfull; j += W) body(std::true_type{}, j, j + W < nfull);
+#endif
         if (nsub > nfull && nfull % W == (uint32_t)w) {  // the image's partial last sub-tile
-            load_sub(nfull, cur, cur_pb, cur_pa);
+            fetch(nfull, cur_pb, cur_pa, cur_raw3);
+            take(cur, cur_raw3);
             body(std::false_type{}, nfull, false);
         }
     } else {
         uint32_t j = w;
-        if (j < nsub) load_sub(j, cur, cur_pb, cur_pa);
+        if (j < nsub) { fetch(j, cur_pb, cur_pa, cur_raw3); take(cur, cur_raw3); }
         for (; j < nsub; j += W) body(std::false_type{}, j, j + W < nsub);
     }
     if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);

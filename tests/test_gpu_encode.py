@@ -259,3 +259,39 @@ def test_pack_streams_into_exact_size_blob(sq, orc):
     for i, wnt in enumerate(wants):
         assert data[off[i]:off[i + 1]] == wnt, i
     plan.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_unaligned_source_and_slot_addresses(sq, orc, mode):
+    """Images and output slots at odd byte addresses (sub-allocations of a caller's arena): the pixel loads
+    (global -> LDS, scalar neighbour loads) and the stream stores must not assume any alignment."""
+    import torch
+
+    o = orc.best()
+    arena = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
+    images, raws, at = [], [], 0
+    for k, (w, h, c, off) in enumerate([(300, 7, 4, 1), (64, 40, 4, 2), (300, 7, 3, 3), (64, 40, 3, 5), (1024, 3, 4, 17),
+                                         (1024, 3, 3, 6), (129, 9, 2, 1), (129, 9, 1, 3), (512, 4, 4, 4), (512, 4, 3, 8)]):
+        if c >= 3:
+            raw = orc.synth(w, h, c, ("mixed", "icon", "photo")[k % 3], 9, k)
+        else:  # mono: smooth ramp + sparse noise, so that LUMA, raw and run ops all occur
+            rng = np.random.default_rng(k)
+            raw = ((np.arange(w * h * c) // 5) + rng.integers(0, 2, w * h * c) * rng.integers(0, 40, w * h * c)).astype(np.uint8)
+        at = (at + 63) // 64 * 64 + off
+        view = arena[at:at + raw.size]
+        view.copy_(torch.from_numpy(raw))
+        assert view.data_ptr() % 64 == off
+        at += raw.size
+        images.append((view, sq.Desc(w, h, c, 0, mode)))
+        raws.append((raw, w, h, c))
+    plan = sq.EncodeList(images)
+    plan.launch()
+    res = plan.results()
+    got = plan.streams()
+    for k, (raw, w, h, c) in enumerate(raws):
+        want = o.encode(raw, w, h, c, mode)
+        if want is None:
+            assert res["status"][k] == 1
+        else:
+            assert res["status"][k] == 0 and got[k] == want, (k, w, h, c)
+    plan.close()
