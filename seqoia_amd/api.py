@@ -139,8 +139,35 @@ def _device_index(t) -> int:
     return t.device.index if t.device.index is not None else 0
 
 
+def image_pitch(nbytes: int) -> int:
+    """Byte distance between consecutive images of a batch arena.
+
+    The workgroups of a batch advance through their images in step; when every image starts on a multiple of a
+    large power of two they all sit on the same address bits at the same time and the encode kernel loses ~12 %
+    (tools/time_stride.py).  One 4 KiB guard page between images takes the batch off that pattern."""
+    return nbytes + 4096 if nbytes % 65536 == 0 else nbytes
+
+
+def alloc_batch(n: int, height: int, width: int, channels: int, device):
+    """uint8 CUDA batch [n, h, w, c] inside one arena with ``image_pitch`` bytes between images (a strided view)."""
+    import torch
+
+    img = height * width * channels
+    pitch = image_pitch(img)
+    arena = torch.empty((max(n, 1) * pitch,), dtype=torch.uint8, device=device)
+    return arena.as_strided((n, height, width, channels), (pitch, width * channels, channels, 1))
+
+
+def _batch_pitch(t) -> int:
+    """Image pitch of a [n, h, w, c] batch whose images are each contiguous (the batch itself may be padded)."""
+    n, h, w, c = t.shape
+    assert t.stride()[1:] == (w * c, c, 1) and (n <= 1 or t.stride(0) >= h * w * c), "images must be contiguous"
+    return t.stride(0) if n > 1 else h * w * c
+
+
 class EncodePlan(Plan):
-    """Encode a batch of same-shaped images held in one torch uint8 CUDA tensor [n, h, w, c].
+    """Encode a batch of same-shaped images held in one torch uint8 CUDA tensor [n, h, w, c]
+    (contiguous, or a padded arena view from ``alloc_batch``).
 
     Output: one worst-case slot per image in ``self.out`` ([n, slot] uint8 on the
     same device); ``results()['len']`` gives the stream length of each.
@@ -149,15 +176,16 @@ class EncodePlan(Plan):
     def __init__(self, pixels, qoi_compat: int = 0, colorspace: int = 0, channels: Optional[int] = None):
         import torch
 
-        assert pixels.is_cuda and pixels.dtype == torch.uint8 and pixels.is_contiguous() and pixels.dim() == 4
+        assert pixels.is_cuda and pixels.dtype == torch.uint8 and pixels.dim() == 4
         n, h, w, c = pixels.shape
+        pitch = _batch_pitch(pixels)
         desc = Desc(w, h, channels if channels is not None else c, colorspace, qoi_compat)
         assert stride_channels(desc.channels) == c
         self.pixels = pixels
         self.slot = encode_bound(desc)
         self.out = torch.empty((n, self.slot), dtype=torch.uint8, device=pixels.device)
-        src0, dst0, img = pixels.data_ptr(), self.out.data_ptr(), h * w * c
-        jobs = [Job(src0 + i * img, dst0 + i * self.slot, 0, self.slot, desc, 0) for i in range(n)]
+        src0, dst0 = pixels.data_ptr(), self.out.data_ptr()
+        jobs = [Job(src0 + i * pitch, dst0 + i * self.slot, 0, self.slot, desc, 0) for i in range(n)]
         super().__init__(ENCODE, jobs, _device_index(pixels))
 
     def streams(self, idx=None):
@@ -202,27 +230,31 @@ class DecodePlan(Plan):
 
     ``streams``: torch uint8 CUDA tensor [n, slot] (e.g. EncodePlan.out) with
     ``lens`` bytes used in each row; every image decodes to width*height*out_channels
-    bytes in ``self.out`` [n, h, w, out_channels].
+    bytes in ``self.out`` [n, h, w, out_channels] (``out``: a caller-provided batch, e.g. from ``alloc_batch``).
     """
 
-    def __init__(self, streams, lens, width: int, height: int, out_channels: int, channels_arg: Optional[int] = None):
+    def __init__(self, streams, lens, width: int, height: int, out_channels: int, channels_arg: Optional[int] = None, out=None):
         import torch
 
         assert streams.is_cuda and streams.dtype == torch.uint8 and streams.is_contiguous() and streams.dim() == 2
         n, slot = streams.shape
         self.streams = streams
-        self.out = torch.empty((n, height, width, out_channels), dtype=torch.uint8, device=streams.device)
+        if out is None:
+            out = torch.empty((n, height, width, out_channels), dtype=torch.uint8, device=streams.device)
+        assert out.is_cuda and out.dtype == torch.uint8 and tuple(out.shape) == (n, height, width, out_channels)
+        self.out = out
+        pitch = _batch_pitch(out)
         arg = out_channels if channels_arg is None else channels_arg
         desc = Desc(width, height, arg, 0, 0)
         src0, dst0, img = streams.data_ptr(), self.out.data_ptr(), height * width * out_channels
-        jobs = [Job(src0 + i * slot, dst0 + i * img, int(lens[i]), img, desc, 0) for i in range(n)]
+        jobs = [Job(src0 + i * slot, dst0 + i * pitch, int(lens[i]), img, desc, 0) for i in range(n)]
         super().__init__(DECODE, jobs, _device_index(streams))
 
 
 def synth(out, cls: str = "mixed", seed: int = 1, img0: int = 0):
     """Fill a torch uint8 CUDA tensor [n, h, w, c] (c in 3,4) with the synthetic images of SURVEY.md Appendix C."""
     n, h, w, c = out.shape
-    assert out.is_cuda and out.is_contiguous()
+    assert out.is_cuda
     kinds = {"mixed": 0, "icon": 1, "photo": 2}
-    check(_lib.load().sqoa_hip_synth(_device_index(out), out.data_ptr(), h * w * c, w, h, c, kinds[cls], seed, img0, n), "sqoa_hip_synth")
+    check(_lib.load().sqoa_hip_synth(_device_index(out), out.data_ptr(), _batch_pitch(out), w, h, c, kinds[cls], seed, img0, n), "sqoa_hip_synth")
     return out

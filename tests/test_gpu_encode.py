@@ -295,3 +295,32 @@ def test_unaligned_source_and_slot_addresses(sq, orc, mode):
         else:
             assert res["status"][k] == 0 and got[k] == want, (k, w, h, c)
     plan.close()
+
+
+def test_padded_batch_arena_matches_contiguous_batch(sq, orc):
+    """alloc_batch() spaces the images of a batch by image_pitch(); streams and decoded pixels are those of the
+    contiguous batch (and of the oracle), and the guard bytes between the images are never written."""
+    import torch
+
+    n, h, w, c = 5, 128, 128, 4  # 64 KiB images: image_pitch adds the guard page
+    assert sq.image_pitch(h * w * c) == h * w * c + 4096
+    flat = torch.empty((n, h, w, c), dtype=torch.uint8, device="cuda")
+    sq.synth(flat, "mixed", 3, 0)
+    pad = sq.alloc_batch(n, h, w, c, flat.device)
+    guard = torch.as_strided(pad, (n, 4096), (pad.stride(0), 1), pad.storage_offset() + h * w * c)
+    guard.fill_(0xA5)
+    sq.synth(pad, "mixed", 3, 0)
+    assert torch.equal(pad, flat) and not pad.is_contiguous()
+    o = orc.best()
+    for mode in (0, 1):
+        a, b = sq.EncodePlan(flat, qoi_compat=mode), sq.EncodePlan(pad, qoi_compat=mode)
+        a.launch(); b.launch()
+        sa, sb = a.streams(), b.streams()
+        assert sa == sb and sa[0] == o.encode(flat[0].cpu().numpy().reshape(-1), w, h, c, mode)
+        out = sq.alloc_batch(n, h, w, c, flat.device)
+        gout = torch.as_strided(out, (n, 4096), (out.stride(0), 1), out.storage_offset() + h * w * c)
+        gout.fill_(0x5A)
+        dec = sq.DecodePlan(b.out, b.results()["len"], w, h, c, out=out)
+        dec.launch()
+        assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, flat)
+        assert (gout == 0x5A).all() and (guard == 0xA5).all()
