@@ -80,6 +80,18 @@ SQOA_DEV unsigned long long lds_read8(const uint32_t* base, uint32_t off) {
     return (unsigned long long)hi << 32 | lo;
 }
 
+// x >> 31 (arithmetic): 0xffffffff where x is "negative".  Opaque to the optimiser on purpose: it would turn the mask
+// arithmetic of the walk back into v_cmp + v_cndmask pairs, which cost 1.7x the add / and / shift they replace
+// (tools/ubench/valu_table.hip: add, sub, and, or, xor, not, mov, lshr, ashr and bitop3 on VGPR / literal operands issue
+// at ~1.0 ns per wave and SIMD, every other VALU instruction -- and any of those with an SGPR operand -- at ~1.73 ns).
+SQOA_DEV uint32_t sra31(uint32_t x) {
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+typedef const __attribute__((address_space(3))) uint32_t* lcptr32;
+typedef const __attribute__((address_space(3))) u32x4* lcptr128;
+
 // bytewise (mod 256) add / sub of four packed channels
 SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
 SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
@@ -154,6 +166,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                                                              sqoa_hip_result* __restrict__ results) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
+    // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
+    //   info: len*8 (6) | len (3) << 6 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
+    __shared__ __attribute__((aligned(16))) u32x4 s_optab[257];
+    // byte -> {ALPHA suffix: delta << 24 | 8, else 0 ;  0 for an ALPHA suffix byte, else ~0}
+    __shared__ __attribute__((aligned(8))) uint32_t s_sfx[256][2];
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
@@ -195,7 +212,20 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
         const uint32_t fA = (b0 - 0x60u) < 0x20u ? (uint32_t)ST_N : opn;
         s_ftab[b0] = fA | opn << 8 | 0x02000000u;
+        // op decode of seqoia.h:740-775 as a table
+        const bool is_abs = b0 >= 0xfeu, is_luma = (b0 & 0xc0u) == 0x80u, is_run = (b0 - 0xc0u) < 0x3eu, is_sfx = (b0 - 0x60u) < 0x20u;
+        const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+        const uint32_t vg = (b0 & 0x3fu) - 32u;
+        u32x4 e;
+        e.x = len * 8u | len << 6 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
+        e.y = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
+        e.z = is_luma ? (((vg - 8u) & 0xffu) | ((vg - 8u) & 0xffu) << 16) : 0u;
+        e.w = is_luma ? ((vg & 0xffu) << 8 | 0x000f000fu) : 0u;
+        s_optab[b0] = e;
+        s_sfx[b0][0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 8u) : 0u;
+        s_sfx[b0][1] = is_sfx ? 0u : 0xffffffffu;
     }
+    if (threadIdx.x == 0) { u32x4 z = {0u, 0u, 0u, 0u}; s_optab[256] = z; }
     __syncthreads();
     if (s_path != 1) return;
 
@@ -282,56 +312,68 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         uint32_t amask[DEC_LB]; // byte mask of the channels of val[] that are absolute
         Xf T{0u, 0u};
         uint32_t cl = 0, iters = DEC_LB, longest = 0;
-        bool ref_lane = false;
+        uint32_t info_or = 0;  // OR of the ops' table words: bit 20 = a lane met SQOA_OP_REF
+        // LDS byte address of my first stream byte; the op tables sit at fixed LDS addresses
+        const uint32_t lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u) + DEC_LB * lane;
+        const uint32_t optab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u32x4*)s_optab;
+        const uint32_t sfx_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_sfx[0][0];
+        // 8 stream bytes at LDS byte address a: three aligned dwords and two v_alignbyte_b32 (an unaligned ds_read_b64 stalls the pipe)
+        auto window = [&](uint32_t a, uint32_t& lo, uint32_t& hi) {
+            lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
+            hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+        };
 #pragma unroll
         for (int i = 0; i < DEC_LB; ++i) {
             // op byte, <= 4 data bytes, possible ALPHA suffix
             if (i == 0) {  // an ALPHA byte at my first op boundary belongs to the op in front of it: step over it
-                const uint32_t f0 = (lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB))) & 0xffu;
-                if (sfx_ok && (f0 - 0x60u) < 0x20u) pos += 1u;
+                uint32_t f0, f1;
+                window(lane_addr + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB), f0, f1);
+                if (sfx_ok && ((f0 & 0xffu) - 0x60u) < 0x20u) pos += 1u;
             }
-            const unsigned long long q = lds_read8(lds, (gs & 3u) + DEC_LB * lane + (pos < (uint32_t)DEC_LB ? pos : (uint32_t)DEC_LB));
-            const uint32_t b0 = (uint32_t)q & 0xffu;
-            const bool act = pos < nlive;
-            if (__ballot(act) == 0ull) {
-#pragma unroll
-                for (int r = i; r < DEC_LB; ++r) { val[r] = 0; meta[r] = 0; amask[r] = 0; }
+            if (__ballot(pos < nlive) == 0ull) {  // val / meta / amask beyond `iters` stay unwritten and unread
                 iters = i;
                 break;
             }
-            ref_lane |= act && b0 < 0x60u;  // SQOA_OP_REF: checked once after the walk (what follows it in this lane is discarded)
-            const uint32_t b1 = ((uint32_t)q >> 8) & 0xffu;
-            const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
-            const uint32_t sb = (uint32_t)(q >> (8u * len)) & 0xffu;  // byte after the op (seqoia.h:777-783)
-            const bool has_sfx = (sb - 0x60u) < 0x20u;
-            const uint32_t da = has_sfx ? ((sb & 31u) - 16u) & 0xffu : 0u;
-            // branch-free decode of the three op families (divergent branches cost more issue slots than the selects)
-            const bool is_abs = b0 >= 0xfeu, is_luma = (b0 & 0xc0u) == 0x80u;
-            const uint32_t setm = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
-            const uint32_t base = ((uint32_t)(q >> 8) & 0x00ffffffu) | ((((uint32_t)(q >> 32) & 0xffu) + da) & 0xffu) << 24;  // RGB[A], seqoia.h:740-752
-            const uint32_t vg = (b0 & 0x3fu) - 32u;                                                   // LUMA, seqoia.h:761-769
-            const uint32_t dl = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
-            const uint32_t d8 = (is_luma ? dl : 0u) | da << 24;
-            // RUN / BIGRUN, or 0x60..0x7f in op position (seqoia.h:770-775); everything else is one pixel
-            uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+            // The op decode of seqoia.h:740-783 as table look-ups and mask arithmetic; no compare / select pairs.
+            const uint32_t m_act = sra31(pos - nlive);                     // ~0 while I still have an op (pos < nlive <= 8)
+            uint32_t lo, hi;
+            window(lane_addr + ((pos & m_act) | ((uint32_t)DEC_LB & ~m_act)), lo, hi);
+            const uint32_t idx = (((lo & 0xffu) - 256u) & m_act) + 256u;   // lanes out of ops decode the "no op" entry
+            const u32x4 e = *(lcptr128)(uintptr_t)(optab_addr + idx * 16u);
+            info_or |= e.x;
+            const uint32_t len = (e.x >> 6) & 7u, setm = e.y;
+            uint32_t cnt = (e.x >> 9) & 0x3ffu;
+            // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op
+            const unsigned long long q = (unsigned long long)hi << 32 | lo;
+            const uint32_t w1 = (uint32_t)(q >> (e.x & 63u));
+            const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 & 0xffu) & m_act) * 8u);
+            const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
+            const uint32_t adv = len + (has8 >> 3);
             // A RUN right behind an op repeats exactly the pixel this op produces (pixel pairs, short repeats, split runs):
             // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
-            const uint32_t adv = len + (has_sfx ? 1u : 0u);
-            const uint32_t nb = (uint32_t)(q >> (8u * adv)) & 0xffu, nn = (uint32_t)(q >> (8u * adv + 8u)) & 0xffu;
-            const uint32_t extra = nb == 0xfdu ? 512u : (nb & 0x3fu) + 1u;
             // (a run behind a run also repeats the same pixel; the 10-bit count field is the only limit)
-            const bool fuse = (nb - 0xc0u) < 0x3eu && (nn - 0x60u) >= 0x20u && pos + adv < nlive && cnt + extra < 1024u;
-            cnt += fuse ? extra : 0u;
-            const uint32_t on = act ? 0xffffffffu : 0u;  // lanes that have run out of ops apply the identity
-            T = xf_then(T, Xf{((d8 & ~setm) | (base & setm)) & on, setm & on});
+            const uint32_t w2 = w1 >> has8;
+            const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xffu) * 16u) >> 21;          // 0 unless RUN / BIGRUN
+            const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + ((w2 >> 8) & 0xffu) * 8u + 4u);      // ~0 unless an ALPHA byte follows
+            const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1024u);
+            const uint32_t extra_m = extra & m_fuse;
+            cnt += extra_m;
+            // the pixel transform of the op: absolute channels from the stream, the others as deltas
+            const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
+            const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;                         // LUMA, seqoia.h:761-769
+            const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
+            T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm});
             val[i] = T.v;
-            meta[i] = cl | (cnt & on) << 13;
+            meta[i] = cl | cnt << 13;
             amask[i] = T.abs;
-            cl += cnt & on;
-            longest = longest > (cnt & on) ? longest : (cnt & on);
-            pos += (adv + (fuse ? 1u : 0u)) & on;
+            cl += cnt;
+            longest = longest > cnt ? longest : cnt;
+            pos += adv + ((extra_m + 1023u) >> 10);
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
+        const bool ref_lane = (info_or >> 20) & 1u;  // SQOA_OP_REF (what follows it in a lane is discarded with the image)
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
             if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
             return false;
