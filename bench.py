@@ -102,8 +102,7 @@ def main():
 
     n, s, ch = args.images, args.size, 4
     dev = torch.device("cuda", local)
-    # batch arenas with one 4 KiB guard page between images (seqoia_amd.image_pitch)
-    px = sq.alloc_batch(n, s, s, ch, dev)
+    px = torch.empty((n, s, s, ch), dtype=torch.uint8, device=dev)
     sq.synth(px, "mixed", seed=1, img0=rank * n)  # every rank owns a disjoint slice of the image list
     enc = sq.EncodePlan(px, qoi_compat=0)
     enc.launch()
@@ -112,7 +111,7 @@ def main():
     enc_bytes = int(res["len"].sum())
     dec = None
     try:
-        dec = sq.DecodePlan(enc.out, res["len"], s, s, 4, out=sq.alloc_batch(n, s, s, 4, dev))
+        dec = sq.DecodePlan(enc.out, res["len"], s, s, 4)
         dec.launch()
         dres = dec.results()
         assert (dres["status"] == 0).all(), "decode failed"
@@ -173,7 +172,6 @@ def main():
         "config": {
             "workload": f"{n} x {s}x{s} RGBA (class mixed, seed 1) per GPU: sqoa_encode qoi_compat=0 then sqoa_decode to 4 channels, device-resident",
             "images_per_gpu": n,
-            "image_pitch_bytes": sq.image_pitch(s * s * ch),
             "encoded_bytes_per_gpu": enc_bytes,
             "rate": round(enc_bytes / (pixels * ch), 4),
             "decode_leg": dec is not None,

@@ -12,11 +12,9 @@ from .api import (  # noqa: F401
     EncodeList,
     EncodePlan,
     Plan,
-    alloc_batch,
     decode,
     encode,
     encode_bound,
-    image_pitch,
     read,
     stride_channels,
     synth,

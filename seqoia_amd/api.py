@@ -139,25 +139,6 @@ def _device_index(t) -> int:
     return t.device.index if t.device.index is not None else 0
 
 
-def image_pitch(nbytes: int) -> int:
-    """Byte distance between consecutive images of a batch arena.
-
-    The workgroups of a batch advance through their images in step; when every image starts on a multiple of a
-    large power of two they all sit on the same address bits at the same time and the encode kernel loses ~12 %
-    (tools/time_stride.py).  One 4 KiB guard page between images takes the batch off that pattern."""
-    return nbytes + 4096 if nbytes % 65536 == 0 else nbytes
-
-
-def alloc_batch(n: int, height: int, width: int, channels: int, device):
-    """uint8 CUDA batch [n, h, w, c] inside one arena with ``image_pitch`` bytes between images (a strided view)."""
-    import torch
-
-    img = height * width * channels
-    pitch = image_pitch(img)
-    arena = torch.empty((max(n, 1) * pitch,), dtype=torch.uint8, device=device)
-    return arena.as_strided((n, height, width, channels), (pitch, width * channels, channels, 1))
-
-
 def _batch_pitch(t) -> int:
     """Image pitch of a [n, h, w, c] batch whose images are each contiguous (the batch itself may be padded)."""
     n, h, w, c = t.shape
@@ -167,7 +148,7 @@ def _batch_pitch(t) -> int:
 
 class EncodePlan(Plan):
     """Encode a batch of same-shaped images held in one torch uint8 CUDA tensor [n, h, w, c]
-    (contiguous, or a padded arena view from ``alloc_batch``).
+    (contiguous, or any view whose images are each contiguous: stride(0) is the image pitch).
 
     Output: one worst-case slot per image in ``self.out`` ([n, slot] uint8 on the
     same device); ``results()['len']`` gives the stream length of each.
@@ -230,7 +211,7 @@ class DecodePlan(Plan):
 
     ``streams``: torch uint8 CUDA tensor [n, slot] (e.g. EncodePlan.out) with
     ``lens`` bytes used in each row; every image decodes to width*height*out_channels
-    bytes in ``self.out`` [n, h, w, out_channels] (``out``: a caller-provided batch, e.g. from ``alloc_batch``).
+    bytes in ``self.out`` [n, h, w, out_channels] (``out``: a caller-provided batch, possibly with a larger image pitch).
     """
 
     def __init__(self, streams, lens, width: int, height: int, out_channels: int, channels_arg: Optional[int] = None, out=None):

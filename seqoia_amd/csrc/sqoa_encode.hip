@@ -132,6 +132,13 @@ SQOA_DEV uint32_t sconst() {  // a constant the compiler must keep in an SGPR (u
     return r;
 }
 
+template <uint32_t V>
+SQOA_DEV uint32_t vconst() {  // a constant held in a VGPR: bitop3 takes no literal, and an SGPR operand halves its issue rate
+    uint32_t r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "n"(V));
+    return r;
+}
+
 struct RunOut { uint32_t lo, n, big; };
 // Bytes owned by a pixel that repeats its predecessor (seqoia.h:544-561, :640-642): 0xfd on every 512th pixel
 // of a run and on a trailing run, the flush (owned by the run's last pixel) otherwise; flushes longer than one
@@ -159,10 +166,23 @@ struct SwarGroup { uint32_t W0, W1, W2, W3, AH, b0, Nn; };  // bytes 0..3 and 4 
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
 template <bool QOI>
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
-    const uint32_t H = sconst<0x80808080u>(), L = sconst<0x7f7f7f7fu>();
-    const uint32_t C08 = sconst<0x08080808u>(), C20 = sconst<0x20202020u>(), C10 = sconst<0x10101010u>();
-    const uint32_t MF0 = sconst<0xf0f0f0f0u>(), MC0 = sconst<0xc0c0c0c0u>(), ME0 = sconst<0xe0e0e0e0u>(), M0F = sconst<0x0f0f0f0fu>();
-    const uint32_t C60 = sconst<0x60606060u>(), CFE = sconst<0xfefefefeu>();
+#ifndef SQOA_ENC_CONST
+#define SQOA_ENC_CONST 1
+#endif
+#if SQOA_ENC_CONST == 0
+#define KC(V) sconst<V>()
+#define KV(V) sconst<V>()
+#elif SQOA_ENC_CONST == 1
+#define KC(V) (V)
+#define KV(V) (V)
+#else
+#define KC(V) (V)
+#define KV(V) vconst<V>()
+#endif
+    const uint32_t H = KV(0x80808080u), L = KV(0x7f7f7f7fu);
+    const uint32_t C08 = KC(0x08080808u), C20 = KC(0x20202020u), C10 = KC(0x10101010u);
+    const uint32_t MF0 = KC(0xf0f0f0f0u), MC0 = KC(0xc0c0c0c0u), ME0 = KC(0xe0e0e0e0u), M0F = KC(0x0f0f0f0fu);
+    const uint32_t C60 = KC(0x60606060u), CFE = KC(0xfefefefeu);
     auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
     auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
     uint32_t c0 = pb;  // pixel in front of the group's first row

@@ -298,17 +298,21 @@ def test_unaligned_source_and_slot_addresses(sq, orc, mode):
 
 
 def test_padded_batch_arena_matches_contiguous_batch(sq, orc):
-    """alloc_batch() spaces the images of a batch by image_pitch(); streams and decoded pixels are those of the
-    contiguous batch (and of the oracle), and the guard bytes between the images are never written."""
+    """A batch whose images are spaced further apart than their size (a strided [n, h, w, c] view of an arena):
+    streams and decoded pixels are those of the contiguous batch (and of the oracle), and the bytes between the
+    images are never written."""
     import torch
 
-    n, h, w, c = 5, 128, 128, 4  # 64 KiB images: image_pitch adds the guard page
-    assert sq.image_pitch(h * w * c) == h * w * c + 4096
+    n, h, w, c, gap = 5, 128, 128, 4, 4096
+    img = h * w * c
+
+    def arena():
+        a = torch.full((n * (img + gap),), 0xA5, dtype=torch.uint8, device="cuda")
+        return a, a.as_strided((n, h, w, c), (img + gap, w * c, c, 1)), a.as_strided((n, gap), (img + gap, 1), img)
+
     flat = torch.empty((n, h, w, c), dtype=torch.uint8, device="cuda")
     sq.synth(flat, "mixed", 3, 0)
-    pad = sq.alloc_batch(n, h, w, c, flat.device)
-    guard = torch.as_strided(pad, (n, 4096), (pad.stride(0), 1), pad.storage_offset() + h * w * c)
-    guard.fill_(0xA5)
+    _, pad, guard = arena()
     sq.synth(pad, "mixed", 3, 0)
     assert torch.equal(pad, flat) and not pad.is_contiguous()
     o = orc.best()
@@ -317,10 +321,8 @@ def test_padded_batch_arena_matches_contiguous_batch(sq, orc):
         a.launch(); b.launch()
         sa, sb = a.streams(), b.streams()
         assert sa == sb and sa[0] == o.encode(flat[0].cpu().numpy().reshape(-1), w, h, c, mode)
-        out = sq.alloc_batch(n, h, w, c, flat.device)
-        gout = torch.as_strided(out, (n, 4096), (out.stride(0), 1), out.storage_offset() + h * w * c)
-        gout.fill_(0x5A)
+        _, out, gout = arena()
         dec = sq.DecodePlan(b.out, b.results()["len"], w, h, c, out=out)
         dec.launch()
         assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, flat)
-        assert (gout == 0x5A).all() and (guard == 0xA5).all()
+        assert (gout == 0xA5).all() and (guard == 0xA5).all()
