@@ -95,9 +95,14 @@ SQOA_DEV void literal_op(uint32_t px, uint32_t pv, bool mono, uint32_t& lo, uint
 // One pixel at a wave-uniform address (any alignment) through the scalar cache: the two aligned dwords that hold its
 // first and last byte (never a byte outside them), shifted together.  Upper bytes beyond `ch` are unspecified.
 typedef const __attribute__((address_space(4))) uint32_t* kcptr32;
-SQOA_DEV uint32_t sload_px(unsigned long long addr, int ch) {
-    const uint32_t lo = *(kcptr32)(addr & ~3ull), hi = *(kcptr32)((addr + (unsigned)ch - 1u) & ~3ull);
-    return (uint32_t)(((unsigned long long)hi << 32 | lo) >> (((uint32_t)addr & 3u) * 8u));
+// The loads are only issued here; `value()` shifts the pair together where the pixel is first needed, so that the wave
+// does not sit in s_waitcnt for the scalar cache at the point of issue.
+struct NbrPx {
+    uint32_t lo, hi, sh, orv;
+    SQOA_DEV uint32_t value() const { return (uint32_t)(((unsigned long long)hi << 32 | lo) >> sh) | orv; }
+};
+SQOA_DEV NbrPx sload_px(unsigned long long addr, int ch, uint32_t orv) {
+    return NbrPx{*(kcptr32)(addr & ~3ull), *(kcptr32)((addr + (unsigned)ch - 1u) & ~3ull), ((uint32_t)addr & 3u) * 8u, orv};
 }
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -430,6 +435,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     unsigned long long* trace = (unsigned long long*)((job.dst + job.dst_cap - 32) & ~7ull);
     if (threadIdx.x == 0) { trace[0] = wall_clock64(); trace[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32; }
 #endif
+#ifdef SQOA_TRACE
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#define PHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define PHASE(k) do { } while (0)
+#endif
     EncState st{0};
     const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane
 
@@ -441,21 +452,21 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
     // (64 VGPRs).  The two neighbour pixels are wave-uniform and come through the scalar cache.  Sub-tiles at the image edges,
     // and 1- / 2-byte pixels, are loaded the plain way and stored to the same buffer as canonical dwords.
-    auto fetch = [&](uint32_t j, uint32_t& pb, uint32_t& pa, bool& raw3) {
+    auto fetch = [&](uint32_t j, NbrPx& pb, NbrPx& pa, bool& raw3) {
         const uint32_t base = j * ENC_SUB;
         raw3 = false;
         if (base > 0 && base + ENC_SUB < N && ch == 4) {
             gcptr8 p = src + (size_t)base * 4;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
-            pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4);
-            pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4);
+            pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4, 0u);
+            pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4, 0u);
         } else if (base > 0 && base + ENC_SUB < N && ch == 3) {
             gcptr8 p = src + (size_t)base * 3;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             if (lane < 32) __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
-            pb = sload_px(job.src + (unsigned long long)base * 3 - 3, 3) | 0xff000000u;
-            pa = sload_px(job.src + (unsigned long long)base * 3 + ENC_SUB * 3, 3) | 0xff000000u;
+            pb = sload_px(job.src + (unsigned long long)base * 3 - 3, 3, 0xff000000u);
+            pa = sload_px(job.src + (unsigned long long)base * 3 + ENC_SUB * 3, 3, 0xff000000u);
             raw3 = true;
         } else {
             uint32_t px[ENC_S];
@@ -464,8 +475,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t idx = base + s * 64 + lane;
                 px[s] = idx < N ? load_px(src, idx, ch) : 0u;
             }
-            pb = bcast_first(base ? load_px(src, base - 1, ch) : kPxInit);
-            pa = bcast_first(base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u);
+            pb = NbrPx{bcast_first(base ? load_px(src, base - 1, ch) : kPxInit), 0u, 0u, 0u};
+            pa = NbrPx{bcast_first(base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u), 0u, 0u, 0u};
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) reinterpret_cast<uint32_t*>(pre)[s * 64 + lane] = px[s];
         }
@@ -491,11 +502,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
     auto body = [&](auto sw_tag, uint32_t j, bool more) {
         constexpr bool SW = decltype(sw_tag)::value;
-        uint32_t nxt_pb = 0, nxt_pa = 0;
+        NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
         // cur[] was read from the landing buffer at the end of the previous sub-tile and those reads have long returned
         // (a flush lies in between); the buffer is free for the next sub-tile's pixels
+        PHASE(7);
         if (more) fetch(j + W, nxt_pb, nxt_pa, nxt_raw3);
+        PHASE(0);
 
         const uint32_t base = j * ENC_SUB;
         const uint32_t pb = cur_pb;
@@ -530,6 +543,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 E[s] = __ballot(px == prev && idx < N);
             }
         }
+        PHASE(1);
         uint32_t trail = 0;
         bool all_eq = true;
 #pragma unroll
@@ -582,6 +596,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 __hip_atomic_store(&s_tabtag[(j / W) & 1][w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 
+        PHASE(2);
         // ---- main pass: op bytes, offsets, compaction into LDS -------------------------
         uint32_t sbase = 0;    // bytes staged so far
         if (flat) {
@@ -690,17 +705,21 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         }
         }
 
+        PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's before the stores of the flush join the memory queue
         if (more) {
             take(cur, nxt_raw3);
-            cur_pb = nxt_pb;
-            cur_pa = nxt_pa;
+            cur_pb = nxt_pb.value();
+            cur_pa = nxt_pa.value();
         }
 
+        PHASE(4);
         // ---- output position from the chain, then drain the staging buffer -------------
         const uint32_t pos = j == 0 ? hdr_len : chain_wait(&s_pos[(j - 1) % W], j, st);
+        PHASE(5);
         if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
         flush_stage(stage, sbase, dst + pos, lane);
+        PHASE(6);
         if (last_sub) {  // seqoia.h:644-649
             const uint32_t end = pos + sbase;
             if (lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const uint32_t nfull = N / ENC_SUB;  // sub-tiles that lie fully inside the image
     if (!mono) {
         uint32_t j = w;
-        if (j < nfull) { fetch(j, cur_pb, cur_pa, cur_raw3); take(cur, cur_raw3); }
+        if (j < nfull) { NbrPx b_, a_; fetch(j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
 #if !defined(SQOA_ENC_PRIO) || SQOA_ENC_PRIO
         // Progress-based wave priority.  The SIMD arbiter is oldest-first: of the images sharing a CU the oldest runs at
         // almost solo speed and the youngest finishes alone on a nearly idle CU (tools/trace_encode.py shows the staircase).
@@ -737,16 +756,21 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         for (; j < nfull; j += W) body(std::true_type{}, j, j + W < nfull);
 #endif
         if (nsub > nfull && nfull % W == (uint32_t)w) {  // the image's partial last sub-tile
-            fetch(nfull, cur_pb, cur_pa, cur_raw3);
+            NbrPx b_, a_;
+            fetch(nfull, b_, a_, cur_raw3);
             take(cur, cur_raw3);
+            cur_pb = b_.value(); cur_pa = a_.value();
             body(std::false_type{}, nfull, false);
         }
     } else {
         uint32_t j = w;
-        if (j < nsub) { fetch(j, cur_pb, cur_pa, cur_raw3); take(cur, cur_raw3); }
+        if (j < nsub) { NbrPx b_, a_; fetch(j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
         for (; j < nsub; j += W) body(std::false_type{}, j, j + W < nsub);
     }
     if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);
+#ifdef SQOA_TRACE
+    if (threadIdx.x == 0) { for (int k = 0; k < 8; ++k) trace[-8 + k] = ph[k]; }
+#endif
 }
 
 // ---- launch -----------------------------------------------------------------------------

@@ -30,3 +30,8 @@ ts = np.linspace(0, e.max(), 21)
 print("t_us:resident ", " ".join(f"{t:.0f}:{int(np.sum((s <= t) & (e > t)))}" for t in ts))
 lens = enc.results()["len"]
 print("corr(duration, len) =", np.corrcoef(d, lens)[0, 1].round(3))
+
+ph = enc.out[:, off - 64:off].cpu().numpy().copy().view(np.uint64).reshape(a.images, 8).astype(np.float64)
+tot = ph.sum(1, keepdims=True)
+names = ["fetch issue", "classify", "run chain", "emit", "take (wait next px)", "pos chain wait", "flush", "loop glue"]
+print("wave 0 time by phase (mean % over images):", ", ".join(f"{n} {v:.1f}" for n, v in zip(names, (100 * ph / tot).mean(0))))
