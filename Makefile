@@ -18,7 +18,7 @@ all: lib oracle tools
 
 lib: $(OUT)/libsqoa_mi355x.so
 
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/sqoa_common.h include/sqoa_hip.h include/seqoia.h
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/sqoa_common.h $(CSRC)/sqoa_decode_parts.h include/sqoa_hip.h include/seqoia.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,17 +1,23 @@
-// sqoa_decode.hip -- SQOA / QOI batch decoder for gfx950 (MI355X).
+// sqoa_decode.hip -- the decoders behind the wave-parallel SQOA path, for gfx950 (MI355X).
 //
-// Replaces the reference decoder loop (seqoia.h:722-806) and its header handling
-// (seqoia.h:672-707).  Two device paths share one job table:
+// Replaces the reference decoder loop (seqoia.h:722-806) and its header handling (seqoia.h:672-707) for every
+// stream sqoa_decode_wave.hip declines (SQOA_HIP_ST_SLOWPATH).  One 64-lane workgroup per image:
 //
-//   * decode_serial_kernel: one image per LANE, the full op set exactly as the
-//     reference parses it, including the crafted-input cases (SQOA_OP_REF with
-//     the SQOA_NEXT cursor quirk seqoia.h:418/:729-738, mono streams with a
-//     128-entry index, exhausted streams).  It is the correctness net for
-//     whatever the wave-parallel path declines, and the whole path for tiny
-//     images, where 64 independent images per wave is the right shape anyway.
-//   * decode_wave_kernel (sqoa_decode_wave.hip): the wave-parallel path for
-//     colour streams without REF ops.
-#include "sqoa_common.h"
+//   * decode_qoi (QOI-compat colour streams, 3/4 output channels).  QOI_OP_INDEX makes every later pixel depend on
+//     the VALUES of all earlier ones (the slot is a hash of the value, seqoia.h:785-787), so pixel values cannot be
+//     scanned like SQOA's.  Everything else still runs across the wave, 512 stream bytes at a time: cooperative
+//     staging in LDS, the parser as a scan of transition functions, every lane decoding the ops that start in its 8
+//     bytes into (transform, index slot, pixel count) records laid out in stream order.  Then ONE lane runs the
+//     reference's recurrence over the records -- pixel, colour index -- out of LDS (no global access, ~20
+//     instructions per op), and the wave stores the pixels and expands the runs.  Parallelism across images comes
+//     from the batch: one wave per image, thousands of waves.
+//   * decode_exact: the complete op set exactly as the reference parses it, including the crafted-input cases
+//     (SQOA_OP_REF with the SQOA_NEXT cursor quirk seqoia.h:418/:729-738, mono streams with a 128-entry index,
+//     1/2-channel output, exhausted streams), one lane per image.  It is the correctness net for whatever the two
+//     wave-parallel decoders decline.
+#include <type_traits>
+
+#include "sqoa_decode_parts.h"
 
 namespace sqoa {
 
@@ -54,29 +60,12 @@ struct Cursor {
     }
 };
 
-constexpr int SERIAL_LANES = 64;
-
-// One image per lane.  table layout [slot][lane] so equal slots across lanes never conflict.
-__global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_hip_job* __restrict__ jobs,
-                                                                     const int* __restrict__ job_ids, int n,
-                                                                     sqoa_hip_result* __restrict__ results, int only_slowpath) {
-    __shared__ uint32_t s_table[128][SERIAL_LANES];
-    const int t = threadIdx.x;
-    const int slot = blockIdx.x * SERIAL_LANES + t;
-    if (slot >= n) return;
-    const int jid = job_ids[slot];
-    const sqoa_hip_job job = jobs[jid];
-    sqoa_hip_result* res = &results[jid];
-    if (only_slowpath) {  // second launch: only what the wave-parallel kernel declined
-        if (res->status != SQOA_HIP_ST_SLOWPATH) return;
-        res->status = SQOA_HIP_ST_OK;
-    }
+// ---- exact decoder, one lane ---------------------------------------------------------------------------------
+// `table`: 128 dwords of LDS private to the calling lane.
+SQOA_DEV void decode_exact(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* res, uint32_t* table) {
     gcptr8 bytes = (gcptr8)job.src;
     gptr8 out = (gptr8)job.dst;
     const int size = (int)job.src_size;
-
-    const Hdr h = parse_header(bytes, res, true);
-    if (!h.ok) { res->status = SQOA_HIP_ST_BADARG; return; }
     const int col = h.channels < 3 ? 1 : 3;
     const uint32_t index_size = col == 1 ? 128u : 64u;  // seqoia.h:690-697
     int channels = job.desc.channels;
@@ -87,7 +76,7 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
     if ((unsigned long long)N * channels > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; return; }
 
     Cursor c{kHeader + (qoi ? 0 : 1), -1, 0};
-    for (int i = 0; i < 128; ++i) s_table[i][t] = 0;
+    for (int i = 0; i < 128; ++i) table[i] = 0;
     uint32_t r = 0, g = 0, b = 0, a = 255;
     int run = 0;
     const int chunks_len = size - 8;
@@ -114,7 +103,7 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
                 else { g = (q >> 8) & 255u; used = 2; }
                 if (b1 == 0xff) { a = (q >> (8 * used)) & 255u; used++; }
             } else if (qoi && (uint32_t)b1 < index_size) {  // seqoia.h:753-755
-                const uint32_t v = s_table[b1][t];
+                const uint32_t v = table[b1];
                 r = v & 255u; g = (v >> 8) & 255u; b = (v >> 16) & 255u; a = v >> 24;
             } else if (qoi && (b1 & 0xc0) == 0x40) {  // seqoia.h:756-760
                 r = (r + ((b1 >> 4) & 3) - 2) & 255u;
@@ -136,7 +125,7 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
                 if (pk >= 0x60 && pk < 0x80) { a = (a + (pk & 31) - 16) & 255u; used++; }
             }
             c.p += used;
-            if (qoi) s_table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size][t] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
+            if (qoi) table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
         }
         else if (c.p < chunks_len) {
             int b1 = bytes[c.next()];
@@ -152,7 +141,7 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
                 else g = bytes[c.next()];
                 if (b1 == 0xff) a = bytes[c.next()];
             } else if (qoi && (uint32_t)b1 < index_size) {  // seqoia.h:753-755
-                const uint32_t v = s_table[b1][t];
+                const uint32_t v = table[b1];
                 r = v & 255u; g = (v >> 8) & 255u; b = (v >> 16) & 255u; a = v >> 24;
             } else if (qoi && (b1 & 0xc0) == 0x40) {  // seqoia.h:756-760
                 r = (r + ((b1 >> 4) & 3) - 2) & 255u;
@@ -175,7 +164,7 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
                     a = (a + (s & 31) - 16) & 255u;
                 }
             }
-            if (qoi) s_table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size][t] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
+            if (qoi) table[(r * 3 + g * 5 + b * 7 + a * 11) % index_size] = r | g << 8 | b << 16 | a << 24;  // seqoia.h:785-787
         }
         gptr8 o = out + (size_t)i * channels;  // seqoia.h:790-805
         if (channels == 4 && (job.dst & 3ull) == 0) {
@@ -190,18 +179,234 @@ __global__ __launch_bounds__(SERIAL_LANES) void decode_serial_kernel(const sqoa_
     res->len = (int)(N * channels);
 }
 
+// ---- QOI-compat colour streams, one wave per image -------------------------------------------------------------
+constexpr int QD_LB = 8;                          // stream bytes per lane
+constexpr int QD_CHUNK = 64 * QD_LB;              // stream bytes per step
+constexpr int QD_LDS_DW = QD_CHUNK / 4 + 8;       // staged dwords: chunk + look-ahead + misalignment
+constexpr int QD_NLD = (QD_LDS_DW + 63) / 64;
+
+struct QoiLds {
+    uint32_t bytes[QD_LDS_DW];
+    uint32_t ftab[256];            // byte -> low half of its parser transition function
+    uint32_t tab[64];              // the colour index (seqoia.h:563, :785-787)
+    uint32_t rec_v[QD_CHUNK + 1];  // per op, in stream order: the transform's value bytes ...
+    uint32_t rec_m[QD_CHUNK + 1];  // ... and 1 = INDEX | absolute-channel code (0, 1 = rgb, 2 = rgba) << 1 | slot << 3
+    uint32_t res[QD_CHUNK];        // pixel after each op
+};
+
+// record meta -> byte mask of the absolute channels
+SQOA_DEV uint32_t qd_amask(uint32_t m) { return (m & 2u) ? 0x00ffffffu : (m & 4u) ? 0xffffffffu : 0u; }
+
+SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* res, QoiLds& L, int lane) {
+    gcptr8 src = (gcptr8)job.src;
+    gptr8 out = (gptr8)job.dst;
+    const uint32_t size = job.src_size;
+    const uint32_t N = h.width * h.height;
+    const int oc = (int)(job.desc.channels ? job.desc.channels : 3u + ((h.channels & 1u) ? 0u : 1u));
+    const uint32_t p0 = kHeader;                // first chunk byte (QOI: right after the header, seqoia.h:705)
+    const uint32_t chunks_len = size - 8;       // seqoia.h:721
+    const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
+    const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
+
+    L.tab[lane] = 0;  // seqoia.h:712
+    for (uint32_t b0 = lane; b0 < 256u; b0 += 64) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
+        const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+        const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
+        L.ftab[b0] = opn | opn << 8 | 0x02000000u;
+    }
+    __syncthreads();
+
+    uint32_t stg[QD_NLD];
+    auto load_chunk = [&](uint32_t c, uint32_t (&r)[QD_NLD]) {
+        const uint32_t d0 = (p0 + c * QD_CHUNK) >> 2;
+#pragma unroll
+        for (int k = 0; k < QD_NLD; ++k) {
+            const uint32_t d = d0 + lane + 64 * k;
+            r[k] = (k < QD_NLD - 1 || lane < QD_LDS_DW - 64 * (QD_NLD - 1)) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+        }
+    };
+    load_chunk(0, stg);
+    uint32_t st_in = ST_A, pos_in = 0, px_in = kPxInit;
+
+    for (uint32_t c = 0; c < nchunks && pos_in < N; ++c) {
+#pragma unroll
+        for (int k = 0; k < QD_NLD - 1; ++k) L.bytes[lane + 64 * k] = stg[k];
+        if (lane < QD_LDS_DW - 64 * (QD_NLD - 1)) L.bytes[lane + 64 * (QD_NLD - 1)] = stg[QD_NLD - 1];
+        if (c + 1 < nchunks) load_chunk(c + 1, stg);
+        const uint32_t gs = p0 + c * QD_CHUNK;
+        const uint32_t my0 = gs + QD_LB * lane;
+        const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)QD_LB ? (uint32_t)QD_LB : chunks_len - my0);
+        const uint32_t loff = (gs & 3u) + QD_LB * lane;
+
+        // ---- parse: the state in front of every lane's first byte ----
+        const unsigned long long own = lds_read8(L.bytes, loff);
+        Fn F{ID_LO, ID_HI};
+#pragma unroll
+        for (int k = 0; k < QD_LB; ++k) {
+            const uint32_t b = (uint32_t)(own >> (8 * k)) & 0xffu;
+            const uint32_t flo = (uint32_t)k < nlive ? L.ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
+            F = compose(Fn{flo, 0x07060403u}, F);
+        }
+        const Fn Fi = wave_compose_scan(F);
+        const Fn G{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)};
+        const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
+        const uint32_t lst = apply(Fx, st_in);
+        st_in = bcast_first(apply(G, st_in));
+
+        // ---- walk: my ops, in order; records are written once their stream-order index is known ----
+        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)QD_LB : 0u);
+        uint32_t rv[QD_LB], rm[QD_LB];  // transform value; record meta | pixel count << 9
+        uint32_t nops = 0, npx = 0, iters = QD_LB, longest = 0;
+#pragma unroll
+        for (int i = 0; i < QD_LB; ++i) {
+            const bool act = pos < nlive;
+            if (__ballot(act) == 0ull) { iters = i; break; }
+            const unsigned long long q = lds_read8(L.bytes, loff + (pos < (uint32_t)QD_LB ? pos : (uint32_t)QD_LB));
+            const uint32_t b0 = (uint32_t)q & 0xffu, b1 = ((uint32_t)q >> 8) & 0xffu;
+            uint32_t v = 0, m = 0, cnt = 1, len = 1;
+            if (b0 >= 0xfeu) {                       // seqoia.h:740-752
+                v = (uint32_t)(q >> 8) & (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu);
+                m = b0 == 0xffu ? 4u : 2u;
+                len = b0 - 0xfau;
+            } else if (b0 < 0x40u) {                 // seqoia.h:753-755
+                m = 1u | b0 << 3;
+            } else if (b0 < 0x80u) {                 // seqoia.h:756-760
+                v = ((((b0 >> 4) & 3u) - 2u) & 0xffu) | ((((b0 >> 2) & 3u) - 2u) & 0xffu) << 8 | (((b0 & 3u) - 2u) & 0xffu) << 16;
+            } else if (b0 < 0xc0u) {                 // seqoia.h:761-769
+                const uint32_t vg = (b0 & 0x3fu) - 32u;
+                v = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
+                len = 2;
+            } else cnt = (b0 & 0x3fu) + 1u;          // seqoia.h:773-775
+            rv[i] = v;
+            rm[i] = act ? (m | cnt << 9) : 0u;
+            nops += act ? 1u : 0u;
+            npx += act ? cnt : 0u;
+            longest = act && cnt > longest ? cnt : longest;
+            pos += act ? len : 0u;
+        }
+
+        // ---- stream-order indices of my ops and pixels, records to LDS ----
+        const uint32_t oinc = wave_incl_scan(nops), pinc = wave_incl_scan(npx);
+        const uint32_t T = bcast_lane(oinc, 63), ptot = bcast_lane(pinc, 63);
+        const uint32_t obase = oinc - nops;
+#pragma unroll
+        for (int i = 0; i < QD_LB; ++i) {
+            if ((uint32_t)i >= iters) break;
+            if (rm[i] >> 9) { L.rec_v[obase + i] = rv[i]; L.rec_m[obase + i] = rm[i]; }
+        }
+        __syncthreads();
+
+        // ---- the recurrence of seqoia.h:740-787 over the records, one lane ----
+        if (lane == 0) {
+            uint32_t px = px_in;
+            uint32_t v = L.rec_v[0], m = L.rec_m[0];
+            for (uint32_t k = 0; k < T; ++k) {
+                const uint32_t vn = L.rec_v[k + 1], mn = L.rec_m[k + 1];  // next record in flight
+                if (m & 1u) px = L.tab[(m >> 3) & 63u];
+                else px = add8(px & ~qd_amask(m), v);
+                L.tab[qoi_hash(px)] = px;
+                L.res[k] = px;
+                v = vn; m = mn;
+            }
+        }
+        __syncthreads();
+
+        // ---- pixels out: literal ops lane-local, runs by the whole wave (seqoia.h:723-725, :790-805) ----
+        uint32_t P = pos_in + pinc - npx;
+        const bool any_long = __ballot(longest > 2u) != 0ull;
+        auto store_ops = [&](auto oc_tag) {
+            constexpr int OC = decltype(oc_tag)::value;
+#pragma unroll
+            for (int i = 0; i < QD_LB; ++i) {
+                if ((uint32_t)i >= iters) break;
+                const uint32_t cnt = rm[i] >> 9;
+                const uint32_t v = cnt ? L.res[obase + i] : 0u;
+                if (cnt >= 1u && cnt <= 2u && P < N) {
+                    if (OC == 4) ((gptr32)out)[P] = v;
+                    else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                }
+                if (cnt == 2u && P + 1u < N) {
+                    if (OC == 4) ((gptr32)out)[P + 1u] = v;
+                    else { gptr8 o = out + (size_t)(P + 1u) * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+                }
+                if (any_long) {
+                    unsigned long long runs = __ballot(cnt > 2u && P < N);
+                    while (runs) {
+                        const int l = __builtin_ctzll(runs);
+                        runs &= runs - 1ull;
+                        const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(v, l);
+                        uint32_t rc = bcast_lane(cnt, l);
+                        if (rp + rc > N) rc = N - rp;
+                        fill_pixels<OC>(out, rp, rc, rvv, lane);
+                    }
+                }
+                P += cnt;
+            }
+        };
+        if (oc == 4 && (job.dst & 3ull) == 0) store_ops(std::integral_constant<int, 4>{});
+        else if (oc == 4) {  // unaligned destination: bytewise
+#pragma unroll
+            for (int i = 0; i < QD_LB; ++i) {
+                if ((uint32_t)i >= iters) break;
+                const uint32_t cnt = rm[i] >> 9;
+                const uint32_t v = cnt ? L.res[obase + i] : 0u;
+                for (uint32_t k = 0; k < cnt && P + k < N; ++k) {
+                    gptr8 o = out + (size_t)(P + k) * 4;
+                    o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 24);
+                }
+                P += cnt;
+            }
+        } else store_ops(std::integral_constant<int, 3>{});
+
+        if (T) px_in = bcast_first(L.res[T - 1]);
+        pos_in = pos_in + ptot > N ? N : pos_in + ptot;
+        __syncthreads();  // L.bytes / records are rewritten by the next chunk
+    }
+    // stream exhausted: the last pixel repeats (seqoia.h:726)
+    if (pos_in < N) {
+        if (oc == 4 && (job.dst & 3ull) == 0) fill_pixels<4>(out, pos_in, N - pos_in, px_in, lane);
+        else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, px_in, lane);
+        else
+            for (uint32_t k = pos_in + lane; k < N; k += 64) {
+                gptr8 o = out + (size_t)k * 4;
+                o[0] = (uint8_t)px_in; o[1] = (uint8_t)(px_in >> 8); o[2] = (uint8_t)(px_in >> 16); o[3] = (uint8_t)(px_in >> 24);
+            }
+    }
+    if (lane == 0) res->len = (int)(N * (uint32_t)oc);
+}
+
+// One image per 64-lane workgroup.
+__global__ __launch_bounds__(64) void decode_fallback_kernel(const sqoa_hip_job* __restrict__ jobs, const int* __restrict__ job_ids,
+                                                            sqoa_hip_result* __restrict__ results, int only_slowpath) {
+    __shared__ QoiLds L;
+    const int lane = threadIdx.x;
+    const int jid = job_ids[blockIdx.x];
+    const sqoa_hip_job job = jobs[jid];
+    sqoa_hip_result* res = &results[jid];
+    if (only_slowpath && res->status != SQOA_HIP_ST_SLOWPATH) return;  // only what the wave-parallel kernel declined
+    __syncthreads();                                                    // every lane has read the status
+    if (only_slowpath && lane == 0) res->status = SQOA_HIP_ST_OK;
+
+    const Hdr h = parse_header((gcptr8)job.src, res, lane == 0);
+    if (!h.ok) { if (lane == 0) res->status = SQOA_HIP_ST_BADARG; return; }
+    const uint32_t oc = job.desc.channels ? job.desc.channels : (h.channels < 3 ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u);
+    const bool wave_ok = h.qoi && h.channels >= 3 && oc >= 3 && (job.src & 3ull) == 0 &&
+                         (unsigned long long)h.width * h.height * oc <= job.dst_cap;
+    if (wave_ok) decode_qoi(job, h, res, L, lane);
+    else if (lane == 0) decode_exact(job, h, res, L.rec_v);
+}
+
 }  // namespace sqoa
 
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
                                               sqoa_hip_result* d_results, hipStream_t stream);
 
-// Wave-parallel kernel first; whatever it marks SQOA_HIP_ST_SLOWPATH goes through the exact serial kernel.
+// Wave-parallel SQOA kernel first; whatever it marks SQOA_HIP_ST_SLOWPATH goes through the fallback kernel.
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipError_t e = sqoa_launch_decode_wave(d_jobs, d_ids, n, d_results, stream);
     if (e != hipSuccess) return e;
-    const int blocks = (n + sqoa::SERIAL_LANES - 1) / sqoa::SERIAL_LANES;
-    hipLaunchKernelGGL(sqoa::decode_serial_kernel, dim3(blocks), dim3(sqoa::SERIAL_LANES), 0, stream, d_jobs, d_ids, n, d_results, 1);
+    hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, 1);
     return hipGetLastError();
 }

@@ -22,7 +22,7 @@
 //      store their pixel directly, runs are expanded cooperatively by the whole wave.
 #include <type_traits>
 
-#include "sqoa_common.h"
+#include "sqoa_decode_parts.h"
 
 #ifndef SQOA_PRIO_T1  // progress (in 64ths of the image) at which a workgroup drops to wave priority 2, 1, 0
 #define SQOA_PRIO_T1 40
@@ -40,61 +40,6 @@ constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wa
 constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded
 constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
 constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
-constexpr uint32_t ID_LO = 0x03020100u, ID_HI = 0x07060504u;  // identity transition function
-
-enum : uint32_t { ST_A = 0, ST_N = 1, ST_X = 6 };
-
-struct Fn { uint32_t lo, hi; };
-
-// (g after f)(s) = g[f(s)]: g is the table, f the selector
-SQOA_DEV Fn compose(Fn g, Fn f) {
-    return Fn{__builtin_amdgcn_perm(g.hi, g.lo, f.lo), __builtin_amdgcn_perm(g.hi, g.lo, f.hi)};
-}
-SQOA_DEV uint32_t apply(Fn f, uint32_t st) { return (uint32_t)(((unsigned long long)f.hi << 32 | f.lo) >> (8u * st)) & 0xffu; }
-
-template <int CTRL, int ROWMASK>
-SQOA_DEV Fn scan_step(Fn F) {
-    Fn P;
-    P.lo = (uint32_t)__builtin_amdgcn_update_dpp((int)ID_LO, (int)F.lo, CTRL, ROWMASK, 0xf, false);
-    P.hi = (uint32_t)__builtin_amdgcn_update_dpp((int)ID_HI, (int)F.hi, CTRL, ROWMASK, 0xf, false);
-    return compose(F, P);
-}
-
-// inclusive composition over the wave: result of lane i = f_i after f_{i-1} after ... after f_0
-SQOA_DEV Fn wave_compose_scan(Fn F) {
-    F = scan_step<DPP_ROW_SHR + 1, 0xf>(F);
-    F = scan_step<DPP_ROW_SHR + 2, 0xf>(F);
-    F = scan_step<DPP_ROW_SHR + 4, 0xf>(F);
-    F = scan_step<DPP_ROW_SHR + 8, 0xf>(F);
-    F = scan_step<DPP_ROW_BCAST15, 0xa>(F);
-    F = scan_step<DPP_ROW_BCAST31, 0xc>(F);
-    return F;
-}
-
-// 8 stream bytes starting at byte offset `off` of a dword array in LDS.  Unaligned ds_read_b64 works on gfx950 but
-// stalls the LDS pipe (SQ_LDS_UNALIGNED_STALL); three aligned dwords and two v_alignbyte_b32 do not.
-SQOA_DEV unsigned long long lds_read8(const uint32_t* base, uint32_t off) {
-    const uint32_t* p = base + (off >> 2);
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, off & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
-    return (unsigned long long)hi << 32 | lo;
-}
-
-// x >> 31 (arithmetic): 0xffffffff where x is "negative".  Opaque to the optimiser on purpose: it would turn the mask
-// arithmetic of the walk back into v_cmp + v_cndmask pairs, which cost 1.7x the add / and / shift they replace
-// (tools/ubench/valu_table.hip: add, sub, and, or, xor, not, mov, lshr, ashr and bitop3 on VGPR / literal operands issue
-// at ~1.0 ns per wave and SIMD, every other VALU instruction -- and any of those with an SGPR operand -- at ~1.73 ns).
-SQOA_DEV uint32_t sra31(uint32_t x) {
-    uint32_t r;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-typedef const __attribute__((address_space(3))) uint32_t* lcptr32;
-typedef const __attribute__((address_space(3))) u32x4* lcptr128;
-
-// bytewise (mod 256) add / sub of four packed channels
-SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
-SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
 
 struct DecShared {
     unsigned long long parse[2];  // per parity: tag<<32 | exit parser state
@@ -115,18 +60,6 @@ SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const
 
 SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
     if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// fill out[p0, p0+cnt) (pixel units) with v; OC = 3 or 4 output channels
-template <int OC>
-SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int lane) {
-    for (uint32_t k = lane; k < cnt; k += 64) {
-        if (OC == 4) ((gptr32)out)[p0 + k] = v;
-        else {
-            gptr8 o = out + (size_t)(p0 + k) * 3;
-            o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
-        }
-    }
 }
 
 // A pixel transform: v8 holds 4 packed channels, `abs` the byte mask of channels that are absolute;
@@ -240,6 +173,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
     uint32_t bad = 0;
 
+#ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#define DPHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define DPHASE(k) do { } while (0)
+#endif
     uint32_t* lds = s_bytes[w];
     uint32_t stg[DEC_NLD];
     // straight-line when the whole staging window lies inside the stream (all but the last chunks): three
@@ -265,6 +204,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     // liveness tests and the end-of-stream handling drop out of the hot loop.  Returns false when the image is handed over.
     auto body = [&](auto in_tag, uint32_t c) -> bool {
         constexpr bool IN = decltype(in_tag)::value;
+        DPHASE(7);
         // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
 #pragma unroll
         for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
@@ -296,10 +236,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const uint32_t g0 = G.lo & 0xffu;
         const bool g_const = G.lo == g0 * 0x01010101u && (G.hi & 0xffffu) == g0 * 0x0101u;
         unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
+        DPHASE(0);
         if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
         if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) return false;
         if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
+        DPHASE(1);
 
         // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
         const uint32_t lst = apply(Fx, st_in);  // parser state in front of my first byte
@@ -379,6 +321,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             return false;
         }
 
+        DPHASE(2);
         // ---- 3. wave scans: pixel positions and pixel transforms of the lanes below ------------
         const uint32_t cinc = wave_incl_scan(cl);
         const uint32_t ctot = bcast_lane(cinc, 63);
@@ -386,12 +329,14 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
         const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
 
+        DPHASE(3);
         // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
         uint32_t pos_in = 0, px_in = kPxInit;
         if (c > 0) {
             if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) return false;
             if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) return false;
         }
+        DPHASE(4);
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
         if (!last_chunk) { post(&s_px[w], c + 1, exit_v, lane); post(&s_pos[w], c + 1, pos_out, lane); }
@@ -444,6 +389,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             else store_ops(std::integral_constant<int, 3>{});
             }
         }
+        DPHASE(5);
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
                 if (oc == 4) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
@@ -480,6 +426,9 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #endif
     for (; go && c < nchunks; c += W) go = body(std::false_type{}, c);
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+#ifdef SQOA_TRACE
+    if (threadIdx.x == 0) { unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull); for (int k = 0; k < 8; ++k) tr[k] = ph[k]; }
+#endif
 }
 
 }  // namespace sqoa
