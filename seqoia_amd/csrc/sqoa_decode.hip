@@ -188,10 +188,9 @@ constexpr int QD_NLD = (QD_LDS_DW + 63) / 64;
 struct QoiLds {
     uint32_t bytes[QD_LDS_DW];
     uint32_t ftab[256];            // byte -> low half of its parser transition function
-    uint32_t tab[64];              // the colour index (seqoia.h:563, :785-787)
-    uint32_t rec_v[QD_CHUNK + 1];  // per op, in stream order: the transform's value bytes ...
-    uint32_t rec_m[QD_CHUNK + 1];  // ... and 1 = INDEX | absolute-channel code (0, 1 = rgb, 2 = rgba) << 1 | slot << 3
-    uint32_t res[QD_CHUNK];        // pixel after each op
+    uint32_t rec_v[QD_CHUNK + 64];  // per op, in stream order: the transform's value bytes ...
+    uint32_t rec_m[QD_CHUNK + 64];  // ... and 1 = INDEX | absolute-channel code (0, 1 = rgb, 2 = rgba) << 1 | slot << 3
+    uint32_t res[QD_CHUNK + 64];    // pixel after each op
 };
 
 // record meta -> byte mask of the absolute channels
@@ -208,7 +207,7 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
 
-    L.tab[lane] = 0;  // seqoia.h:712
+    uint32_t tabv = 0;  // the colour index, slot = lane (seqoia.h:712, :785-787)
     for (uint32_t b0 = lane; b0 < 256u; b0 += 64) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
@@ -226,7 +225,8 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
         }
     };
     load_chunk(0, stg);
-    uint32_t st_in = ST_A, pos_in = 0, px_in = kPxInit;
+    uint32_t st_in = ST_A, pos_in = 0;
+    uint32_t pxv = kPxInit;  // the current pixel, the same in every lane (seqoia.h:716-719)
 
     for (uint32_t c = 0; c < nchunks && pos_in < N; ++c) {
 #pragma unroll
@@ -296,18 +296,27 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
         }
         __syncthreads();
 
-        // ---- the recurrence of seqoia.h:740-787 over the records, one lane ----
-        if (lane == 0) {
-            uint32_t px = px_in;
-            uint32_t v = L.rec_v[0], m = L.rec_m[0];
-            for (uint32_t k = 0; k < T; ++k) {
-                const uint32_t vn = L.rec_v[k + 1], mn = L.rec_m[k + 1];  // next record in flight
-                if (m & 1u) px = L.tab[(m >> 3) & 63u];
-                else px = add8(px & ~qd_amask(m), v);
-                L.tab[qoi_hash(px)] = px;
-                L.res[k] = px;
-                v = vn; m = mn;
+        // ---- the recurrence of seqoia.h:740-787 over the records ----
+        // Register-resident: 64 records at a time are read across the lanes and handed out with v_readlane, the colour
+        // index is ONE VGPR (lane = slot), the results of 64 ops collect in another; the current pixel is kept in a VGPR
+        // (same value in every lane) so that its hash never has to cross to the scalar unit: "index[hash] = px" is a
+        // compare of the hash with the lane id and a select.  No LDS or memory access inside the loop.
+        for (uint32_t g = 0; g < T; g += 64) {
+            const uint32_t vv = L.rec_v[g + lane], mm = L.rec_m[g + lane];
+            const uint32_t ng = T - g < 64u ? T - g : 64u;
+            uint32_t resv = 0;
+            for (uint32_t t = 0; t < ng; ++t) {
+                const uint32_t m = bcast_lane(mm, (int)t);
+                if (m & 1u) {  // QOI_OP_INDEX (seqoia.h:753-755)
+                    pxv = bcast_lane(tabv, (int)((m >> 3) & 63u));
+                } else {
+                    const uint32_t v = bcast_lane(vv, (int)t);
+                    pxv = add8(pxv & ~qd_amask(m), v);
+                }
+                tabv = (uint32_t)lane == qoi_hash(pxv) ? pxv : tabv;   // seqoia.h:785-787
+                resv = (uint32_t)lane == t ? pxv : resv;
             }
+            L.res[g + lane] = resv;
         }
         __syncthreads();
 
@@ -358,18 +367,17 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
             }
         } else store_ops(std::integral_constant<int, 3>{});
 
-        if (T) px_in = bcast_first(L.res[T - 1]);
         pos_in = pos_in + ptot > N ? N : pos_in + ptot;
         __syncthreads();  // L.bytes / records are rewritten by the next chunk
     }
     // stream exhausted: the last pixel repeats (seqoia.h:726)
     if (pos_in < N) {
-        if (oc == 4 && (job.dst & 3ull) == 0) fill_pixels<4>(out, pos_in, N - pos_in, px_in, lane);
-        else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, px_in, lane);
+        if (oc == 4 && (job.dst & 3ull) == 0) fill_pixels<4>(out, pos_in, N - pos_in, pxv, lane);
+        else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, pxv, lane);
         else
             for (uint32_t k = pos_in + lane; k < N; k += 64) {
                 gptr8 o = out + (size_t)k * 4;
-                o[0] = (uint8_t)px_in; o[1] = (uint8_t)(px_in >> 8); o[2] = (uint8_t)(px_in >> 16); o[3] = (uint8_t)(px_in >> 24);
+                o[0] = (uint8_t)pxv; o[1] = (uint8_t)(pxv >> 8); o[2] = (uint8_t)(pxv >> 16); o[3] = (uint8_t)(pxv >> 24);
             }
     }
     if (lane == 0) res->len = (int)(N * (uint32_t)oc);
