@@ -191,7 +191,22 @@ struct QoiLds {
     uint32_t rec_v[QD_CHUNK + 64];  // per op, in stream order: the transform's value bytes ...
     uint32_t rec_m[QD_CHUNK + 64];  // ... and 1 = INDEX | absolute-channel code (0, 1 = rgb, 2 = rgba) << 1 | slot << 3
     uint32_t res[QD_CHUNK + 64];    // pixel after each op
+    uint32_t stamp[64];             // per index slot: stream-order number + 1 of its last writer
 };
+
+// One step of the segmented transform scan: `hf` (all ones / zero) marks lanes whose segment head lies at or below them
+// within the distance covered so far; such lanes keep their transform, the others prepend the one arriving from below.
+template <int CTRL, int ROWMASK>
+SQOA_DEV Xf seg_scan_step(Xf T, uint32_t& hf) {
+    Xf P;
+    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, false);
+    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, false);
+    const uint32_t pf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hf, CTRL, ROWMASK, 0xf, false);
+    const Xf C = xf_then(P, T);
+    const Xf R{(T.v & hf) | (C.v & ~hf), (T.abs & hf) | (C.abs & ~hf)};
+    hf |= pf;
+    return R;
+}
 
 // record meta -> byte mask of the absolute channels
 SQOA_DEV uint32_t qd_amask(uint32_t m) { return (m & 2u) ? 0x00ffffffu : (m & 4u) ? 0xffffffffu : 0u; }
@@ -208,6 +223,9 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
 
     uint32_t tabv = 0;  // the colour index, slot = lane (seqoia.h:712, :785-787)
+    uint32_t seen = 0;  // stamp of the writer tabv holds
+    uint32_t opbase = 0;  // ops before this chunk
+    L.stamp[lane] = 0;
     for (uint32_t b0 = lane; b0 < 256u; b0 += 64) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
@@ -296,28 +314,61 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
         }
         __syncthreads();
 
-        // ---- the recurrence of seqoia.h:740-787 over the records ----
-        // Register-resident: 64 records at a time are read across the lanes and handed out with v_readlane, the colour
-        // index is ONE VGPR (lane = slot), the results of 64 ops collect in another; the current pixel is kept in a VGPR
-        // (same value in every lane) so that its hash never has to cross to the scalar unit: "index[hash] = px" is a
-        // compare of the hash with the lane id and a select.  No LDS or memory access inside the loop.
+        // ---- the recurrence of seqoia.h:740-787 over the records, 64 ops (one per lane) at a time ----
+        // Between two QOI_OP_INDEX ops pixel values do not depend on the colour index: they are one segmented scan of
+        // the ops' transforms (segments start behind every INDEX op) applied to the pixel the segment starts from.  What
+        // stays serial is short: per INDEX op one look-up, per op one "index[hash] = px" (the hash is computed in
+        // parallel; the store is a compare of the lane id with it and a select on the VGPR that holds the index,
+        // lane = slot).  No LDS or memory access inside.
+#ifdef SQOA_QD_SKIP_REC
+        for (uint32_t g = 0; g < T; g += 64) L.res[g + lane] = L.rec_v[g + lane];
+        if (0)
+#endif
         for (uint32_t g = 0; g < T; g += 64) {
-            const uint32_t vv = L.rec_v[g + lane], mm = L.rec_m[g + lane];
             const uint32_t ng = T - g < 64u ? T - g : 64u;
-            uint32_t resv = 0;
-            for (uint32_t t = 0; t < ng; ++t) {
-                const uint32_t m = bcast_lane(mm, (int)t);
-                if (m & 1u) {  // QOI_OP_INDEX (seqoia.h:753-755)
-                    pxv = bcast_lane(tabv, (int)((m >> 3) & 63u));
-                } else {
-                    const uint32_t v = bcast_lane(vv, (int)t);
-                    pxv = add8(pxv & ~qd_amask(m), v);
+            const bool live = (uint32_t)lane < ng;
+            const uint32_t m = live ? L.rec_m[g + lane] : 0u;
+            const bool isx = m & 1u;
+            const uint32_t am = isx ? 0u : qd_amask(m);
+            Xf S{(live && !isx) ? L.rec_v[g + lane] : 0u, am};
+            // segment heads: the group's first op and every op behind an INDEX op
+            uint32_t hf = shift_up1(isx ? ~0u : 0u, ~0u);
+            S = seg_scan_step<DPP_ROW_SHR + 1, 0xf>(S, hf);
+            S = seg_scan_step<DPP_ROW_SHR + 2, 0xf>(S, hf);
+            S = seg_scan_step<DPP_ROW_SHR + 4, 0xf>(S, hf);
+            S = seg_scan_step<DPP_ROW_SHR + 8, 0xf>(S, hf);
+            S = seg_scan_step<DPP_ROW_BCAST15, 0xa>(S, hf);
+            S = seg_scan_step<DPP_ROW_BCAST31, 0xc>(S, hf);
+            unsigned long long idxmask = __ballot(isx);
+            uint32_t s0 = 0, resv = 0;
+            const uint32_t opno = opbase + g;  // stream-order number of the group's first op
+            for (;;) {
+                const uint32_t j = idxmask ? (uint32_t)__builtin_ctzll(idxmask) : ng;  // next INDEX op, or the end of the group
+                const uint32_t pxc = add8(pxv & ~S.abs, S.v);                            // valid in lanes [s0, j)
+                const uint32_t hv = qoi_hash(pxc);
+                const bool inseg = (uint32_t)lane >= s0 && (uint32_t)lane < j;
+                if (inseg) resv = pxc;
+                if (j > s0) {
+                    // seqoia.h:785-787 for the whole segment at once: every op stamps its slot with its stream-order number
+                    // (ds_max: the last writer of a slot wins, as in the reference's in-order stores); the lane that owns a
+                    // slot then fetches the pixel of a writer newer than the one it has already seen
+                    if (inseg) atomicMax(&L.stamp[hv], opno + (uint32_t)lane + 1u);
+                    const uint32_t w = L.stamp[lane];
+                    const uint32_t from = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w - opno - 1u) << 2), (int)pxc);
+                    if (w > seen) { tabv = from; seen = w; }
                 }
-                tabv = (uint32_t)lane == qoi_hash(pxv) ? pxv : tabv;   // seqoia.h:785-787
-                resv = (uint32_t)lane == t ? pxv : resv;
+                if (j > s0) pxv = bcast_lane(pxc, (int)(j - 1u));
+                if (j >= ng) break;
+                pxv = bcast_lane(tabv, (int)((bcast_lane(m, (int)j) >> 3) & 63u));    // seqoia.h:753-755
+                tabv = (uint32_t)lane == qoi_hash(pxv) ? pxv : tabv;
+                if ((uint32_t)lane == j) resv = pxv;
+                idxmask &= idxmask - 1ull;
+                s0 = j + 1u;
+                if (s0 >= ng) break;
             }
             L.res[g + lane] = resv;
         }
+        opbase += T;
         __syncthreads();
 
         // ---- pixels out: literal ops lane-local, runs by the whole wave (seqoia.h:723-725, :790-805) ----

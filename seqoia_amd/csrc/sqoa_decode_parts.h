@@ -74,4 +74,12 @@ SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int 
     }
 }
 
+// A pixel transform: v8 holds 4 packed channels, `abs` the byte mask of channels that are absolute;
+// the other channels are deltas (mod 256) still to be added to whatever pixel enters.
+struct Xf { uint32_t v, abs; };
+// first `a`, then `b`
+// (b.v holds the value itself in b's absolute channels and a delta elsewhere, so masking a's side first is enough)
+SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{add8(a.v & ~b.abs, b.v), a.abs | b.abs}; }
+SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return add8(px & ~t.abs, t.v); }
+
 }  // namespace sqoa

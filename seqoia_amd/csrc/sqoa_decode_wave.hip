@@ -62,14 +62,6 @@ SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lan
     if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// A pixel transform: v8 holds 4 packed channels, `abs` the byte mask of channels that are absolute;
-// the other channels are deltas (mod 256) still to be added to whatever pixel enters.
-struct Xf { uint32_t v, abs; };
-// first `a`, then `b`
-// (b.v holds the value itself in b's absolute channels and a delta elsewhere, so masking a's side first is enough)
-SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{add8(a.v & ~b.abs, b.v), a.abs | b.abs}; }
-SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return add8(px & ~t.abs, t.v); }
-
 template <int CTRL, int ROWMASK>
 SQOA_DEV Xf xf_scan_step(Xf T) {
     Xf P;  // the transform of the lanes below, identity where there is none
