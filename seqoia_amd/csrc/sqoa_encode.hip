@@ -382,7 +382,10 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 #ifndef SQOA_ENC_WPE
 #define SQOA_ENC_WPE 8
 #endif
-#define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SQOA_ENC_WPE, SQOA_ENC_WPE)))
+#ifndef SQOA_ENC_WPE_QOI
+#define SQOA_ENC_WPE_QOI 4
+#endif
+#define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(QOI ? SQOA_ENC_WPE_QOI : SQOA_ENC_WPE, QOI ? 6 : SQOA_ENC_WPE)))
 template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
