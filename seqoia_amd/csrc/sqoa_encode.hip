@@ -4,7 +4,7 @@
 // its tail (seqoia.h:640-649).  Dataflow, per image:
 //
 //   * the image is cut into sub-tiles of 512 pixels = 8 rows of 64; sub-tile j is owned by wave (j mod W) of the
-//     image's workgroup, which walks j, j+W, j+2W, ... with the next sub-tile's loads in flight;
+//     image's workgroup, which walks j, j+W, j+2W, ... while the next sub-tile's pixels land in LDS (global_load_lds);
 //   * colour images take the SWAR path: the op decision (LUMA / ALPHA / RGB[A], DIFF in QOI mode) is made for the
 //     same lane of FOUR rows at once, bytewise inside dwords (swar_classify); per row follow run bookkeeping from
 //     the __ballot equality masks, byte offsets from DPP prefix sums, and variable-length compaction by OR-ing
@@ -124,26 +124,12 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
 
 
 // ---- SWAR main pass: four 64-pixel rows at a time, one byte lane per row -------------------------------
-// gfx950 issues 4-byte VOP2 encodings at twice the rate of the 8-byte VOP3 / SDWA / DPP ones
-// (tools/ubench/valu_rate.hip), and the per-pixel op decision (seqoia.h:584-635) is all 8-bit arithmetic.
+// gfx950 issues add / sub / logic / right-shift / bitop3 on VGPR or literal operands at 1.7x the rate of every other
+// VALU instruction (tools/ubench/valu_table.hip), and the per-pixel op decision (seqoia.h:584-635) is all 8-bit arithmetic.
 // So the decision is made for the same lane of FOUR rows at once: the four pixels are transposed into one
 // dword per channel (v_perm_b32), channel deltas, the vg_r / vg_b terms, the range tests and the LUMA
 // byte fields are computed bytewise inside dwords with plain and/or/add/sub/xor, and only the final
 // assembly of each pixel's bytes and its LDS store is done per row.
-template <uint32_t V>
-SQOA_DEV uint32_t sconst() {  // a constant the compiler must keep in an SGPR (usable as VOP2 src0, no literal dword)
-    uint32_t r;
-    asm("s_mov_b32 %0, %1" : "=s"(r) : "n"(V));
-    return r;
-}
-
-template <uint32_t V>
-SQOA_DEV uint32_t vconst() {  // a constant held in a VGPR: bitop3 takes no literal, and an SGPR operand halves its issue rate
-    uint32_t r;
-    asm("v_mov_b32 %0, %1" : "=v"(r) : "n"(V));
-    return r;
-}
-
 struct RunOut { uint32_t lo, n, big; };
 // Bytes owned by a pixel that repeats its predecessor (seqoia.h:544-561, :640-642): 0xfd on every 512th pixel
 // of a run and on a trailing run, the flush (owned by the run's last pixel) otherwise; flushes longer than one
@@ -171,23 +157,11 @@ struct SwarGroup { uint32_t W0, W1, W2, W3, AH, b0, Nn; };  // bytes 0..3 and 4 
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
 template <bool QOI>
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
-#ifndef SQOA_ENC_CONST
-#define SQOA_ENC_CONST 1
-#endif
-#if SQOA_ENC_CONST == 0
-#define KC(V) sconst<V>()
-#define KV(V) sconst<V>()
-#elif SQOA_ENC_CONST == 1
-#define KC(V) (V)
-#define KV(V) (V)
-#else
-#define KC(V) (V)
-#define KV(V) vconst<V>()
-#endif
-    const uint32_t H = KV(0x80808080u), L = KV(0x7f7f7f7fu);
-    const uint32_t C08 = KC(0x08080808u), C20 = KC(0x20202020u), C10 = KC(0x10101010u);
-    const uint32_t MF0 = KC(0xf0f0f0f0u), MC0 = KC(0xc0c0c0c0u), ME0 = KC(0xe0e0e0e0u), M0F = KC(0x0f0f0f0fu);
-    const uint32_t C60 = KC(0x60606060u), CFE = KC(0xfefefefeu);
+    // constants as literals: an SGPR operand would put the add / and / or they feed into the slow VALU class
+    const uint32_t H = 0x80808080u, L = 0x7f7f7f7fu;
+    const uint32_t C08 = 0x08080808u, C20 = 0x20202020u, C10 = 0x10101010u;
+    const uint32_t MF0 = 0xf0f0f0f0u, MC0 = 0xc0c0c0c0u, ME0 = 0xe0e0e0e0u, M0F = 0x0f0f0f0fu;
+    const uint32_t C60 = 0x60606060u, CFE = 0xfefefefeu;
     auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
     auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
     uint32_t c0 = pb;  // pixel in front of the group's first row
@@ -232,7 +206,7 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
         } else {
             // QOI-compat ops for a pixel that missed the index (seqoia.h:573-634): alpha moved -> RGBA; else DIFF if
             // vr, vg, vb in [-2, 1]; else LUMA; else RGB
-            const uint32_t C02 = sconst<0x02020202u>(), MFC = sconst<0xfcfcfcfcu>(), C40 = sconst<0x40404040u>(), ONE = sconst<0x01010101u>();
+            const uint32_t C02 = 0x02020202u, MFC = 0xfcfcfcfcu, C40 = 0x40404040u, ONE = 0x01010101u;
             const uint32_t ER = ((DR & L) + C02) ^ (DR & H), EG = ((DG & L) + C02) ^ (DG & H), EB = ((DB & L) + C02) ^ (DB & H);  // v + 2
             const uint32_t z0 = nz(DR | DG | DB | DA), z2 = nz(DA);
             const uint32_t zd = nz((ER | EG | EB) & MFC);                  // 0x80: DIFF does not fit
@@ -245,7 +219,7 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
             const uint32_t lu_mask = ~na_mask & nd_mask & ~nl_mask;        // LUMA
             const uint32_t rw_mask = na_mask | (nd_mask & nl_mask);        // RGB or RGBA: r g b follow the tag
             // seqoia.h:599; the shifts run across byte lanes, so every field is masked to its own two bits
-            const uint32_t DIFFB = C40 | ((ER << 4) & sconst<0x30303030u>()) | ((EG << 2) & sconst<0x0c0c0c0cu>()) | (EB & sconst<0x03030303u>());
+            const uint32_t DIFFB = C40 | ((ER << 4) & 0x30303030u) | ((EG << 2) & 0x0c0c0c0cu) | (EB & 0x03030303u);
             const uint32_t L0 = XG | H, L1 = ((XR << 4) & MF0) | (XB & M0F);
             o.W0 = ((DIFFB & df_mask) | (L0 & lu_mask) | (CFE & rw_mask) | (ONE & na_mask)) & ne_mask;  // 0xfe | 1 = 0xff
             o.W1 = ((L1 & lu_mask) | (R & rw_mask)) & ne_mask;
@@ -781,8 +755,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    // 8 waves per image: the kernel is VALU-issue bound (most of its ops are 8-byte VOP3/SDWA/DPP encodings,
-    // which issue at half the rate of 4-byte VOP2 on gfx950: tools/ubench/valu_rate.hip), more resident waves help
+    // 8 waves per image, four images per CU: the kernel is VALU-issue bound (tools/ubench/valu_table.hip)
 #ifndef SQOA_ENC_W
 #define SQOA_ENC_W 8
 #endif
