@@ -92,7 +92,9 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
-    //   info: len*8 (6) | len (3) << 6 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
+    //   info: len (3) | (len*8 - 4) (6) << 3 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
+    //   (the stream window is shifted 4 bits short of the op's end, so that the following bytes sit at bits 4.., 12..:
+    //    byte * 16 and byte * 8, the table strides, are then a mask or a right shift away -- v_lshlrev_b32 is slow-class)
     __shared__ __attribute__((aligned(16))) u32x4 s_optab[257];
     // byte -> {ALPHA suffix: delta << 24 | 8, else 0 ;  0 for an ALPHA suffix byte, else ~0}
     __shared__ __attribute__((aligned(8))) uint32_t s_sfx[256][2];
@@ -142,15 +144,15 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
         const uint32_t vg = (b0 & 0x3fu) - 32u;
         u32x4 e;
-        e.x = len * 8u | len << 6 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
+        e.x = len | (len * 8u - 4u) << 3 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
         e.y = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
         e.z = is_luma ? (((vg - 8u) & 0xffu) | ((vg - 8u) & 0xffu) << 16) : 0u;
         e.w = is_luma ? ((vg & 0xffu) << 8 | 0x000f000fu) : 0u;
         s_optab[b0] = e;
-        s_sfx[b0][0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 8u) : 0u;
+        s_sfx[b0][0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 9u) : 0u;  // delta << 24 | 8 (shift) | 1 (length)
         s_sfx[b0][1] = is_sfx ? 0u : 0xffffffffu;
     }
-    if (threadIdx.x == 0) { u32x4 z = {0u, 0u, 0u, 0u}; s_optab[256] = z; }
+    if (threadIdx.x == 0) { u32x4 z = {4u << 3, 0u, 0u, 0u}; s_optab[256] = z; }
     __syncthreads();
     if (s_path != 1) return;
 
@@ -277,20 +279,20 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const uint32_t idx = (((lo & 0xffu) - 256u) & m_act) + 256u;   // lanes out of ops decode the "no op" entry
             const u32x4 e = *(lcptr128)(uintptr_t)(optab_addr + idx * 16u);
             info_or |= e.x;
-            const uint32_t len = (e.x >> 6) & 7u, setm = e.y;
+            const uint32_t len = e.x & 7u, setm = e.y;
             uint32_t cnt = (e.x >> 9) & 0x3ffu;
-            // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op
+            // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op.  w1 = stream >> (8 * len - 4).
             const unsigned long long q = (unsigned long long)hi << 32 | lo;
-            const uint32_t w1 = (uint32_t)(q >> (e.x & 63u));
-            const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 & 0xffu) & m_act) * 8u);
+            const uint32_t w1 = (uint32_t)(q >> ((e.x >> 3) & 63u));
+            const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 >> 1) & 0x7f8u & m_act));
             const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
-            const uint32_t adv = len + (has8 >> 3);
+            const uint32_t adv = len + (se & 1u);
             // A RUN right behind an op repeats exactly the pixel this op produces (pixel pairs, short repeats, split runs):
             // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
             // (a run behind a run also repeats the same pixel; the 10-bit count field is the only limit)
             const uint32_t w2 = w1 >> has8;
-            const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xffu) * 16u) >> 21;          // 0 unless RUN / BIGRUN
-            const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + ((w2 >> 8) & 0xffu) * 8u + 4u);      // ~0 unless an ALPHA byte follows
+            const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
+            const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + 4u + ((w2 >> 9) & 0x7f8u));          // ~0 unless an ALPHA byte follows
             const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1024u);
             const uint32_t extra_m = extra & m_fuse;
             cnt += extra_m;
