@@ -72,8 +72,8 @@ def cpu_baseline(width, height, channels, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps; the first ~50 ms after an idle period run at lower clocks (tools/time_warm.py)")
     ap.add_argument("--images", type=int, default=1024, help="images per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true")

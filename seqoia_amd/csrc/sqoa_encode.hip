@@ -241,6 +241,9 @@ template <bool QOI>
 SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
                             uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask, uint32_t* tabw,
                             unsigned long long* smask) {
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+    const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
+    const uint32_t sink_addr = stage_addr + (uint32_t)ENC_STG + 4u * lane;
     uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
     cr[0] = c_in;
 #pragma unroll
@@ -321,14 +324,15 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
         for (int i = 0; i < 4; ++i) {
             const uint32_t n = (Nn >> (8 * i)) & 255u;
             const uint32_t incl = ((i < 2 ? i01 : i23) >> (16 * (i & 1))) & 0xffffu;
-            const uint32_t o = rowbase[i] + incl - n;
+            const uint32_t o = (rowbase[i] + stage_addr) + incl - n;  // LDS byte address (the base is 16-byte aligned)
             uint32_t lo = lo4[i], hi = (G.AH >> (8 * i)) & 255u;
             if (QOI && hitv[i]) { lo = hitv[i] & 63u; hi = 0; }
             const uint32_t sh = (o & 3u) * 8u;
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
             // pixels that emit nothing send their zero to a private sink instead of being masked off: no exec juggling,
             // and no 64 lanes OR-ing the same dword
-            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (n ? (o & ~3u) : (uint32_t)ENC_STG + 4u * lane));
+            // (LDS addresses: the staging buffer is 16-byte aligned, so its base rides on the wave-uniform row base for free)
+            lds_u32 p = (lds_u32)(uintptr_t)(n ? (o & ~3u) : sink_addr);
             __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             obig[i] = o;
@@ -341,7 +345,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 #pragma nounroll
                     for (uint32_t t = 0; t <= q; ++t) {
                         const uint32_t ob = obig[i] + t;
-                        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (ob & ~3u)), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
+                        __hip_atomic_fetch_or((lds_u32)(uintptr_t)(ob & ~3u), (t == q ? last : 0xfcu) << ((ob & 3u) * 8u),
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                 }

@@ -328,3 +328,43 @@ def test_batch_decode_random_bodies_match_oracle(sq, orc):
                     assert res["status"][i] == 0, (w, h, oc, i, int(res["status"][i]))
                     assert out[i].tobytes() == want.tobytes(), (w, h, oc, i)
             dec.close()
+
+
+def test_qoi_long_random_streams_match_oracle(sq, orc):
+    """QOI-compat bodies of random ops over dozens of 512-byte steps: INDEX ops (a quarter of random bytes) at every
+    position of the 64-op groups and across step boundaries, look-ups of slots nobody has written, runs that pass the
+    end of the image.  The wave-parallel QOI decoder (segmented transform scan + stamped index updates) must agree with
+    the reference byte for byte."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(77)
+    w = h = 256
+    streams = []
+    for k in range(16):
+        n = int(rng.integers(9000, 40000))
+        body = rng.integers(0, 256, size=n, dtype=np.uint8)
+        if k % 4 == 1:   # few runs: the image is not exhausted early
+            body = np.where((body >= 0xc0) & (body < 0xfe), body & 0x3f, body).astype(np.uint8)
+        if k % 4 == 2:   # two-colour ping-pong through the index between literal pixels
+            body[::3] = rng.integers(0, 4, size=len(body[::3]))
+        hdr_ch = (4, 3)[k & 1]
+        streams.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([hdr_ch, 0]) + body.tobytes() + bytes(7) + b"\x01")
+    slot = max(len(s) for s in streams) + 32
+    buf = np.zeros((len(streams), slot), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    dev = torch.from_numpy(buf).cuda()
+    for oc in (4, 3):
+        wants = [o.decode(s, oc)[0] for s in streams]
+        dec = sq.DecodePlan(dev, [len(s) for s in streams], w, h, oc)
+        dec.launch()
+        res = dec.results()
+        out = dec.out.cpu().numpy()
+        for i, want in enumerate(wants):
+            if want is None:  # a body that happens to start with 0x31 reads as "qoif" + SQOA start byte: refused (seqoia.h:677, :683)
+                assert res["status"][i] != 0, (oc, i)
+                continue
+            assert res["status"][i] == 0 and res["qoi_compat"][i] == 1, (oc, i)
+            assert out[i].tobytes() == want.tobytes(), (oc, i)
+        dec.close()
