@@ -9,6 +9,15 @@
 
 #define SQOA_DEV __device__ __forceinline__
 
+// s_sleep argument (x 64 cycles) between two polls of a chain word: a polling wave spends scalar-pipe slots, which the
+// kernels are short of (tools/ubench/salu_mix.hip)
+#ifndef SQOA_ENC_SPIN_SLEEP
+#define SQOA_ENC_SPIN_SLEEP 8   // encode 2.13 -> 2.09 ms against 1; the decoder's shorter chunks prefer 1 (3.87 vs 4.03 ms at 8)
+#endif
+#ifndef SQOA_DEC_SPIN_SLEEP
+#define SQOA_DEC_SPIN_SLEEP 1
+#endif
+
 namespace sqoa {
 
 // Device addresses arrive as integers in the job table; tell the compiler they are GLOBAL

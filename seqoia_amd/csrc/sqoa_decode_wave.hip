@@ -52,7 +52,7 @@ SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
         if (bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
     }
     bad = 1;
     return false;

@@ -45,7 +45,7 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t hi = bcast_first((uint32_t)(v >> 32));
         if (hi == tag) return bcast_first((uint32_t)v);
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
     }
     st.bad = 1;
     return 0;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     const uint32_t t = __hip_atomic_load(&s_tabtag[pp][pw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (bcast_first(t) == j) break;
                     if (spin >= SPIN_MAX) { st.bad = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
                 }
                 tin = s_tabpub[pp][pw % QW][lane];
             }
