@@ -2,8 +2,8 @@
 //
 // Replaces the serial parse of the reference decoder (seqoia.h:722-806) for streams whose ops
 // are RGB/RGBA, LUMA(+ALPHA suffix), RUN/BIGRUN (SQOA) -- i.e. everything the encoder emits.
-// Streams with SQOA_OP_REF, mono streams, QOI streams and 1/2-channel outputs are handed to the
-// exact serial kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
+// Streams with SQOA_OP_REF, mono streams, QOI-compat streams and 1/2-channel outputs are handed to
+// decode_fallback_kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
 //
 // Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W, and
 // inside a chunk every lane owns DEC_LB = 8 consecutive stream bytes):
@@ -14,7 +14,8 @@
 //      chunk's total function is usually constant (the byte stream re-synchronises), so the exit state
 //      is published before the entry state is even known: the parse chain does not serialise.
 //   2. walk: knowing the state in front of its first byte, a lane decodes its own <= 8 ops in order,
-//      each from 8 bytes of LDS (op byte, <= 4 data bytes, possible ALPHA suffix), branch-free.  A pixel
+//      each from 8 bytes of LDS (op byte, <= 4 data bytes, possible ALPHA suffix): LDS table look-ups and
+//      mask arithmetic, no compare / select chains (they are slow-class VALU).  A pixel
 //      transform is (v, abs): per-channel value, absolute or still a delta mod 256; the lane keeps the
 //      transform after each op and its pixel counts.
 //   3. scans: one DPP prefix sum of the lanes' pixel counts, one DPP scan composing the lanes' transforms.
@@ -33,7 +34,7 @@
 namespace sqoa {
 
 #ifndef SQOA_DEC_LB
-#define SQOA_DEC_LB 8  /* 16 halves the per-chunk scans but costs occupancy (109 VGPRs): 9.8 ms vs 7.2 ms */
+#define SQOA_DEC_LB 8  /* 12 / 16 amortise the per-chunk scans but spill: 5.5 ms (12, per-op records packed) vs 3.87 ms */
 #endif
 constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane
 constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step)
