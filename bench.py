@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--images", type=int, default=1024, help="images per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the step once into a HIP graph and replay it (same time: launch overhead is not what bounds the step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -129,15 +130,32 @@ def main():
         if dec is not None:
             dec.launch(stream)
 
+    # plan launches allocate nothing and never touch the host, so the step is captured once into a HIP graph and replayed
+    graph = None
+    if args.graph:
+        try:
+            step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=work_stream):
+                step()
+            run = graph.replay
+        except Exception as e:  # noqa: BLE001 -- the direct path is always available
+            if rank == 0:
+                print(f"[bench] HIP graph capture unavailable ({e}); launching directly", file=sys.stderr)
+            graph = None
+    if graph is None:
+        run = step
+
     for _ in range(args.warmup):
-        step()
+        run()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -175,6 +193,7 @@ def main():
             "encoded_bytes_per_gpu": enc_bytes,
             "rate": round(enc_bytes / (pixels * ch), 4),
             "decode_leg": dec is not None,
+            "launch": "hip graph replay" if graph is not None else "direct",
             "encode_mpps_per_gpu": round(pixels / enc_ms / 1e3, 1),
             "decode_mpps_per_gpu": round(pixels / dec_ms / 1e3, 1) if dec_ms else None,
         },
