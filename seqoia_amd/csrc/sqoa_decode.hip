@@ -1,16 +1,17 @@
 // sqoa_decode.hip -- the decoders behind the wave-parallel SQOA path, for gfx950 (MI355X).
 //
 // Replaces the reference decoder loop (seqoia.h:722-806) and its header handling (seqoia.h:672-707) for every
-// stream sqoa_decode_wave.hip declines (SQOA_HIP_ST_SLOWPATH).  One 64-lane workgroup per image:
+// stream sqoa_decode_wave.hip declines (SQOA_HIP_ST_SLOWPATH).  One workgroup of two waves per image:
 //
 //   * decode_qoi (QOI-compat colour streams, 3/4 output channels).  QOI_OP_INDEX makes every later pixel depend on
 //     the VALUES of all earlier ones (the slot is a hash of the value, seqoia.h:785-787), so pixel values cannot be
 //     scanned like SQOA's.  Everything else still runs across the wave, 512 stream bytes at a time: cooperative
 //     staging in LDS, the parser as a scan of transition functions, every lane decoding the ops that start in its 8
-//     bytes into (transform, index slot, pixel count) records laid out in stream order.  Then ONE lane runs the
-//     reference's recurrence over the records -- pixel, colour index -- out of LDS (no global access, ~20
-//     instructions per op), and the wave stores the pixels and expands the runs.  Parallelism across images comes
-//     from the batch: one wave per image, thousands of waves.
+//     bytes into (transform, index slot, pixel count) records laid out in stream order (wave 0).  Wave 1 runs the
+//     reference's recurrence over the records, 64 ops at a time: pixel values between two INDEX ops by a segmented
+//     scan of the transforms, index updates by per-slot stamps, one serial look-up per INDEX op; then it stores the
+//     pixels and expands the runs.  The two waves are coupled by double-buffered record arrays in LDS.  Parallelism
+//     across images comes from the batch: one workgroup per image, thousands of workgroups.
 //   * decode_exact: the complete op set exactly as the reference parses it, including the crafted-input cases
 //     (SQOA_OP_REF with the SQOA_NEXT cursor quirk seqoia.h:418/:729-738, mono streams with a 128-entry index,
 //     1/2-channel output, exhausted streams), one lane per image.  It is the correctness net for whatever the two
@@ -187,11 +188,15 @@ constexpr int QD_NLD = (QD_LDS_DW + 63) / 64;
 
 struct QoiLds {
     uint32_t bytes[QD_LDS_DW];
-    uint32_t ftab[256];            // byte -> low half of its parser transition function
-    uint32_t rec_v[QD_CHUNK + 64];  // per op, in stream order: the transform's value bytes ...
-    uint32_t rec_m[QD_CHUNK + 64];  // ... and 1 = INDEX | absolute-channel code (0, 1 = rgb, 2 = rgba) << 1 | slot << 3
-    uint32_t res[QD_CHUNK + 64];    // pixel after each op
-    uint32_t stamp[64];             // per index slot: stream-order number + 1 of its last writer
+    uint32_t ftab[256];               // byte -> low half of its parser transition function
+    // per op, in stream order, double-buffered between the two waves: the transform's value bytes and
+    // 1 = INDEX | absolute-channel code (2 = rgb, 4 = rgba) | slot << 3 | pixel count << 9
+    uint32_t rec_v[2][QD_CHUNK + 64];
+    uint16_t rec_m[2][QD_CHUNK + 64];  // (15 bits: QOI runs are <= 62 pixels)
+    uint32_t nrec[2];                 // ops in each buffer
+    uint32_t ready[2], freed[2];      // chunk number + 1 that filled / released each buffer
+    uint32_t stop;                    // the image is complete: the front wave may leave
+    uint32_t stamp[64];               // per index slot: stream-order number + 1 of its last writer
 };
 
 // One step of the segmented transform scan: `hf` (all ones / zero) marks lanes whose segment head lies at or below them
@@ -211,27 +216,28 @@ SQOA_DEV Xf seg_scan_step(Xf T, uint32_t& hf) {
 // record meta -> byte mask of the absolute channels
 SQOA_DEV uint32_t qd_amask(uint32_t m) { return (m & 2u) ? 0x00ffffffu : (m & 4u) ? 0xffffffffu : 0u; }
 
-SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* res, QoiLds& L, int lane) {
+constexpr uint32_t QD_SPIN_MAX = 1u << 24;
+
+// Wait until *flag reaches `want` (flags only grow) or the image is declared complete; false = leave.
+template <int SLEEP>
+SQOA_DEV bool qd_wait(uint32_t* flag, uint32_t want, uint32_t* stop, uint32_t& bad) {
+    for (uint32_t spin = 0; spin < QD_SPIN_MAX; ++spin) {
+        if (bcast_first(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= want) return true;
+        if (bcast_first(__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+        __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    bad = 1;
+    return false;
+}
+
+// Front wave: stage, parse, decode ops into stream-order records (everything that does not depend on pixel values).
+SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& bad) {
     gcptr8 src = (gcptr8)job.src;
-    gptr8 out = (gptr8)job.dst;
     const uint32_t size = job.src_size;
-    const uint32_t N = h.width * h.height;
-    const int oc = (int)(job.desc.channels ? job.desc.channels : 3u + ((h.channels & 1u) ? 0u : 1u));
     const uint32_t p0 = kHeader;                // first chunk byte (QOI: right after the header, seqoia.h:705)
     const uint32_t chunks_len = size - 8;       // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
-
-    uint32_t tabv = 0;  // the colour index, slot = lane (seqoia.h:712, :785-787)
-    uint32_t seen = 0;  // stamp of the writer tabv holds
-    uint32_t opbase = 0;  // ops before this chunk
-    L.stamp[lane] = 0;
-    for (uint32_t b0 = lane; b0 < 256u; b0 += 64) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
-        const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
-        const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
-        L.ftab[b0] = opn | opn << 8 | 0x02000000u;
-    }
-    __syncthreads();
 
     uint32_t stg[QD_NLD];
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[QD_NLD]) {
@@ -243,10 +249,10 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
         }
     };
     load_chunk(0, stg);
-    uint32_t st_in = ST_A, pos_in = 0;
-    uint32_t pxv = kPxInit;  // the current pixel, the same in every lane (seqoia.h:716-719)
+    uint32_t st_in = ST_A;
 
-    for (uint32_t c = 0; c < nchunks && pos_in < N; ++c) {
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t buf = c & 1u;
 #pragma unroll
         for (int k = 0; k < QD_NLD - 1; ++k) L.bytes[lane + 64 * k] = stg[k];
         if (lane < QD_LDS_DW - 64 * (QD_NLD - 1)) L.bytes[lane + 64 * (QD_NLD - 1)] = stg[QD_NLD - 1];
@@ -271,10 +277,10 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
         const uint32_t lst = apply(Fx, st_in);
         st_in = bcast_first(apply(G, st_in));
 
-        // ---- walk: my ops, in order; records are written once their stream-order index is known ----
+        // ---- walk: my ops, in order ----
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)QD_LB : 0u);
-        uint32_t rv[QD_LB], rm[QD_LB];  // transform value; record meta | pixel count << 9
-        uint32_t nops = 0, npx = 0, iters = QD_LB, longest = 0;
+        uint32_t rv[QD_LB], rm[QD_LB];
+        uint32_t nops = 0, iters = QD_LB;
 #pragma unroll
         for (int i = 0; i < QD_LB; ++i) {
             const bool act = pos < nlive;
@@ -298,41 +304,59 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
             rv[i] = v;
             rm[i] = act ? (m | cnt << 9) : 0u;
             nops += act ? 1u : 0u;
-            npx += act ? cnt : 0u;
-            longest = act && cnt > longest ? cnt : longest;
             pos += act ? len : 0u;
         }
 
-        // ---- stream-order indices of my ops and pixels, records to LDS ----
-        const uint32_t oinc = wave_incl_scan(nops), pinc = wave_incl_scan(npx);
-        const uint32_t T = bcast_lane(oinc, 63), ptot = bcast_lane(pinc, 63);
+        // ---- records in stream order, handed to the back wave ----
+        const uint32_t oinc = wave_incl_scan(nops);
+        const uint32_t T = bcast_lane(oinc, 63);
         const uint32_t obase = oinc - nops;
+        if (c >= 2u && !qd_wait<16>(&L.freed[buf], c - 1u, &L.stop, bad)) return;  // (polls rarely: it runs ahead of the back wave)  // chunk c-2 has left this buffer
 #pragma unroll
         for (int i = 0; i < QD_LB; ++i) {
             if ((uint32_t)i >= iters) break;
-            if (rm[i] >> 9) { L.rec_v[obase + i] = rv[i]; L.rec_m[obase + i] = rm[i]; }
+            if (rm[i] >> 9) { L.rec_v[buf][obase + i] = rv[i]; L.rec_m[buf][obase + i] = (uint16_t)rm[i]; }
         }
-        __syncthreads();
+        if (lane == 0) L.nrec[buf] = T;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&L.ready[buf], c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (bcast_first(__hip_atomic_load(&L.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
+    }
+}
 
-        // ---- the recurrence of seqoia.h:740-787 over the records, 64 ops (one per lane) at a time ----
+// Back wave: the recurrence of seqoia.h:740-787 over the records, 64 ops (one per lane) at a time, and the pixels.
+SQOA_DEV void qoi_back(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* res, QoiLds& L, int lane, uint32_t& bad) {
+    gptr8 out = (gptr8)job.dst;
+    const uint32_t size = job.src_size;
+    const uint32_t N = h.width * h.height;
+    const int oc = (int)(job.desc.channels ? job.desc.channels : 3u + ((h.channels & 1u) ? 0u : 1u));
+    const uint32_t p0 = kHeader, chunks_len = size - 8;
+    const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
+    const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
+    const bool dw_out = oc == 4 && (job.dst & 3ull) == 0;
+
+    uint32_t tabv = 0;   // the colour index, slot = lane (seqoia.h:712, :785-787)
+    uint32_t seen = 0;   // stamp of the writer tabv holds
+    uint32_t opno = 0;   // stream-order number of the current group's first op
+    uint32_t pos_in = 0;
+    uint32_t pxv = kPxInit;  // the current pixel, the same in every lane (seqoia.h:716-719)
+
+    for (uint32_t c = 0; c < nchunks && pos_in < N; ++c) {
+        const uint32_t buf = c & 1u;
+        if (!qd_wait<1>(&L.ready[buf], c + 1u, &L.stop, bad)) break;
+        const uint32_t T = bcast_first(L.nrec[buf]);
         // Between two QOI_OP_INDEX ops pixel values do not depend on the colour index: they are one segmented scan of
-        // the ops' transforms (segments start behind every INDEX op) applied to the pixel the segment starts from.  What
-        // stays serial is short: per INDEX op one look-up, per op one "index[hash] = px" (the hash is computed in
-        // parallel; the store is a compare of the lane id with it and a select on the VGPR that holds the index,
-        // lane = slot).  No LDS or memory access inside.
-#ifdef SQOA_QD_SKIP_REC
-        for (uint32_t g = 0; g < T; g += 64) L.res[g + lane] = L.rec_v[g + lane];
-        if (0)
-#endif
-        for (uint32_t g = 0; g < T; g += 64) {
+        // the ops' transforms (segments start behind every INDEX op) applied to the pixel the segment starts from.
+        // "index[hash] = px" for a whole segment is one ds_max of stream-order stamps per op (the last writer of a slot
+        // wins, as in the reference's in-order stores) and one fetch by the lane that owns the slot; what stays serial
+        // is one look-up per INDEX op.  The index itself is one VGPR, lane = slot.
+        for (uint32_t g = 0; g < T; g += 64, opno += 64) {
             const uint32_t ng = T - g < 64u ? T - g : 64u;
             const bool live = (uint32_t)lane < ng;
-            const uint32_t m = live ? L.rec_m[g + lane] : 0u;
+            const uint32_t m = live ? L.rec_m[buf][g + lane] : 0u;
             const bool isx = m & 1u;
-            const uint32_t am = isx ? 0u : qd_amask(m);
-            Xf S{(live && !isx) ? L.rec_v[g + lane] : 0u, am};
-            // segment heads: the group's first op and every op behind an INDEX op
-            uint32_t hf = shift_up1(isx ? ~0u : 0u, ~0u);
+            Xf S{(live && !isx) ? L.rec_v[buf][g + lane] : 0u, isx ? 0u : qd_amask(m)};
+            uint32_t hf = shift_up1(isx ? ~0u : 0u, ~0u);  // segment heads: the group's first op and every op behind an INDEX op
             S = seg_scan_step<DPP_ROW_SHR + 1, 0xf>(S, hf);
             S = seg_scan_step<DPP_ROW_SHR + 2, 0xf>(S, hf);
             S = seg_scan_step<DPP_ROW_SHR + 4, 0xf>(S, hf);
@@ -341,7 +365,6 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
             S = seg_scan_step<DPP_ROW_BCAST31, 0xc>(S, hf);
             unsigned long long idxmask = __ballot(isx);
             uint32_t s0 = 0, resv = 0;
-            const uint32_t opno = opbase + g;  // stream-order number of the group's first op
             for (;;) {
                 const uint32_t j = idxmask ? (uint32_t)__builtin_ctzll(idxmask) : ng;  // next INDEX op, or the end of the group
                 const uint32_t pxc = add8(pxv & ~S.abs, S.v);                            // valid in lanes [s0, j)
@@ -349,15 +372,12 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
                 const bool inseg = (uint32_t)lane >= s0 && (uint32_t)lane < j;
                 if (inseg) resv = pxc;
                 if (j > s0) {
-                    // seqoia.h:785-787 for the whole segment at once: every op stamps its slot with its stream-order number
-                    // (ds_max: the last writer of a slot wins, as in the reference's in-order stores); the lane that owns a
-                    // slot then fetches the pixel of a writer newer than the one it has already seen
                     if (inseg) atomicMax(&L.stamp[hv], opno + (uint32_t)lane + 1u);
                     const uint32_t w = L.stamp[lane];
                     const uint32_t from = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w - opno - 1u) << 2), (int)pxc);
                     if (w > seen) { tabv = from; seen = w; }
+                    pxv = bcast_lane(pxc, (int)(j - 1u));
                 }
-                if (j > s0) pxv = bcast_lane(pxc, (int)(j - 1u));
                 if (j >= ng) break;
                 pxv = bcast_lane(tabv, (int)((bcast_lane(m, (int)j) >> 3) & 63u));    // seqoia.h:753-755
                 tabv = (uint32_t)lane == qoi_hash(pxv) ? pxv : tabv;
@@ -366,64 +386,48 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
                 s0 = j + 1u;
                 if (s0 >= ng) break;
             }
-            L.res[g + lane] = resv;
+            // ---- pixels of these 64 ops: literal ops lane-local, runs by the whole wave (seqoia.h:723-725, :790-805) ----
+            const uint32_t cnt = m >> 9;
+            const uint32_t pinc = wave_incl_scan(cnt);
+            const uint32_t P = pos_in + pinc - cnt;
+            const bool any_long = __ballot(cnt > 2u) != 0ull;
+            if (dw_out) {
+                if (cnt >= 1u && cnt <= 2u && P < N) ((gptr32)out)[P] = resv;
+                if (cnt == 2u && P + 1u < N) ((gptr32)out)[P + 1u] = resv;
+            } else {
+                for (uint32_t k = 0; k < cnt && k < 2u && cnt <= 2u && P + k < N; ++k) {
+                    gptr8 o = out + (size_t)(P + k) * (unsigned)oc;
+                    o[0] = (uint8_t)resv; o[1] = (uint8_t)(resv >> 8); o[2] = (uint8_t)(resv >> 16);
+                    if (oc == 4) o[3] = (uint8_t)(resv >> 24);
+                }
+            }
+            if (any_long) {
+                unsigned long long runs = __ballot(cnt > 2u && P < N);
+                while (runs) {
+                    const int l = __builtin_ctzll(runs);
+                    runs &= runs - 1ull;
+                    const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(resv, l);
+                    uint32_t rc = bcast_lane(cnt, l);
+                    if (rp + rc > N) rc = N - rp;
+                    if (dw_out) fill_pixels<4>(out, rp, rc, rvv, lane);
+                    else if (oc == 3) fill_pixels<3>(out, rp, rc, rvv, lane);
+                    else
+                        for (uint32_t k = lane; k < rc; k += 64) {
+                            gptr8 o = out + (size_t)(rp + k) * 4;
+                            o[0] = (uint8_t)rvv; o[1] = (uint8_t)(rvv >> 8); o[2] = (uint8_t)(rvv >> 16); o[3] = (uint8_t)(rvv >> 24);
+                        }
+                }
+            }
+            const uint32_t ptot = bcast_lane(pinc, 63);
+            pos_in = pos_in + ptot > N ? N : pos_in + ptot;
         }
-        opbase += T;
-        __syncthreads();
-
-        // ---- pixels out: literal ops lane-local, runs by the whole wave (seqoia.h:723-725, :790-805) ----
-        uint32_t P = pos_in + pinc - npx;
-        const bool any_long = __ballot(longest > 2u) != 0ull;
-        auto store_ops = [&](auto oc_tag) {
-            constexpr int OC = decltype(oc_tag)::value;
-#pragma unroll
-            for (int i = 0; i < QD_LB; ++i) {
-                if ((uint32_t)i >= iters) break;
-                const uint32_t cnt = rm[i] >> 9;
-                const uint32_t v = cnt ? L.res[obase + i] : 0u;
-                if (cnt >= 1u && cnt <= 2u && P < N) {
-                    if (OC == 4) ((gptr32)out)[P] = v;
-                    else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
-                }
-                if (cnt == 2u && P + 1u < N) {
-                    if (OC == 4) ((gptr32)out)[P + 1u] = v;
-                    else { gptr8 o = out + (size_t)(P + 1u) * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
-                }
-                if (any_long) {
-                    unsigned long long runs = __ballot(cnt > 2u && P < N);
-                    while (runs) {
-                        const int l = __builtin_ctzll(runs);
-                        runs &= runs - 1ull;
-                        const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(v, l);
-                        uint32_t rc = bcast_lane(cnt, l);
-                        if (rp + rc > N) rc = N - rp;
-                        fill_pixels<OC>(out, rp, rc, rvv, lane);
-                    }
-                }
-                P += cnt;
-            }
-        };
-        if (oc == 4 && (job.dst & 3ull) == 0) store_ops(std::integral_constant<int, 4>{});
-        else if (oc == 4) {  // unaligned destination: bytewise
-#pragma unroll
-            for (int i = 0; i < QD_LB; ++i) {
-                if ((uint32_t)i >= iters) break;
-                const uint32_t cnt = rm[i] >> 9;
-                const uint32_t v = cnt ? L.res[obase + i] : 0u;
-                for (uint32_t k = 0; k < cnt && P + k < N; ++k) {
-                    gptr8 o = out + (size_t)(P + k) * 4;
-                    o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 24);
-                }
-                P += cnt;
-            }
-        } else store_ops(std::integral_constant<int, 3>{});
-
-        pos_in = pos_in + ptot > N ? N : pos_in + ptot;
-        __syncthreads();  // L.bytes / records are rewritten by the next chunk
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&L.freed[buf], c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (lane == 0) __hip_atomic_store(&L.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // stream exhausted: the last pixel repeats (seqoia.h:726)
-    if (pos_in < N) {
-        if (oc == 4 && (job.dst & 3ull) == 0) fill_pixels<4>(out, pos_in, N - pos_in, pxv, lane);
+    if (pos_in < N && !bad) {
+        if (dw_out) fill_pixels<4>(out, pos_in, N - pos_in, pxv, lane);
         else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, pxv, lane);
         else
             for (uint32_t k = pos_in + lane; k < N; k += 64) {
@@ -434,25 +438,40 @@ SQOA_DEV void decode_qoi(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result*
     if (lane == 0) res->len = (int)(N * (uint32_t)oc);
 }
 
-// One image per 64-lane workgroup.
-__global__ __launch_bounds__(64) void decode_fallback_kernel(const sqoa_hip_job* __restrict__ jobs, const int* __restrict__ job_ids,
-                                                            sqoa_hip_result* __restrict__ results, int only_slowpath) {
+// One image per workgroup of two waves.
+__global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job* __restrict__ jobs, const int* __restrict__ job_ids,
+                                                             sqoa_hip_result* __restrict__ results, int only_slowpath) {
     __shared__ QoiLds L;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
+    const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];
     const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
     if (only_slowpath && res->status != SQOA_HIP_ST_SLOWPATH) return;  // only what the wave-parallel kernel declined
     __syncthreads();                                                    // every lane has read the status
-    if (only_slowpath && lane == 0) res->status = SQOA_HIP_ST_OK;
+    if (only_slowpath && threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;
 
-    const Hdr h = parse_header((gcptr8)job.src, res, lane == 0);
-    if (!h.ok) { if (lane == 0) res->status = SQOA_HIP_ST_BADARG; return; }
+    const Hdr h = parse_header((gcptr8)job.src, res, threadIdx.x == 0);
+    if (!h.ok) { if (threadIdx.x == 0) res->status = SQOA_HIP_ST_BADARG; return; }
     const uint32_t oc = job.desc.channels ? job.desc.channels : (h.channels < 3 ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u);
     const bool wave_ok = h.qoi && h.channels >= 3 && oc >= 3 && (job.src & 3ull) == 0 &&
                          (unsigned long long)h.width * h.height * oc <= job.dst_cap;
-    if (wave_ok) decode_qoi(job, h, res, L, lane);
-    else if (lane == 0) decode_exact(job, h, res, L.rec_v);
+    if (!wave_ok) {
+        if (threadIdx.x == 0) decode_exact(job, h, res, &L.rec_v[0][0]);  // (the record buffers are free: 128 dwords of colour index)
+        return;
+    }
+    // QOI-compat colour stream: wave 0 turns bytes into op records, wave 1 turns records into pixels (seqoia.h:722-806)
+    if (threadIdx.x < 64) { L.stamp[lane] = 0; if (lane < 2) { L.ready[lane] = 0; L.freed[lane] = 0; L.nrec[lane] = 0; } if (lane == 0) L.stop = 0; }
+    for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += 128) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
+        const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+        const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
+        L.ftab[b0] = opn | opn << 8 | 0x02000000u;
+    }
+    __syncthreads();
+    uint32_t bad = 0;
+    if (w == 0) qoi_front(job, L, lane, bad);
+    else qoi_back(job, h, res, L, lane, bad);
+    if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 }
 
 }  // namespace sqoa
@@ -466,6 +485,6 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n <= 0) return hipSuccess;
     hipError_t e = sqoa_launch_decode_wave(d_jobs, d_ids, n, d_results, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, 1);
+    hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(128), 0, stream, d_jobs, d_ids, d_results, 1);
     return hipGetLastError();
 }
