@@ -89,6 +89,12 @@ int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 /* Wait for the plan's stream and copy the n results to host memory. */
 int sqoa_hip_plan_results(sqoa_hip_plan *plan, sqoa_hip_result *out, int n);
 
+/* One-shot forms of the batch extension SURVEY.md section 8(b) asks for ("sqoa_encode_batch / sqoa_decode_batch": an
+ * array of descriptors and device buffers in, output slots + lengths out): create a plan on `device`, launch it, wait,
+ * copy the n results to `results`, destroy the plan.  Synchronous; callers that repeat a batch shape keep a plan instead. */
+int sqoa_hip_encode_batch(int device, const sqoa_hip_job *jobs, int n, sqoa_hip_result *results);
+int sqoa_hip_decode_batch(int device, const sqoa_hip_job *jobs, int n, sqoa_hip_result *results);
+
 /* Launch `iters` times back to back on the plan's own stream between two HIP
  * events recorded on that stream; *ms_total receives the elapsed time. */
 int sqoa_hip_plan_time(sqoa_hip_plan *plan, int iters, float *ms_total);

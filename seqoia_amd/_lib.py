@@ -71,6 +71,8 @@ SYMBOLS = {
     "sqoa_hip_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sqoa_hip_plan_results": (C.c_int, [C.c_void_p, C.POINTER(Result), C.c_int]),
     "sqoa_hip_plan_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "sqoa_hip_encode_batch": (C.c_int, [C.c_int, C.POINTER(Job), C.c_int, C.POINTER(Result)]),
+    "sqoa_hip_decode_batch": (C.c_int, [C.c_int, C.POINTER(Job), C.c_int, C.POINTER(Result)]),
     "sqoa_hip_pack": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_size_t, C.c_ulonglong, C.POINTER(C.c_ulonglong), C.c_void_p]),
     "sqoa_hip_synth": (C.c_int, [C.c_int, C.c_ulonglong, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_int]),
     "sqoa_hip_fnv1a64": (C.c_int, [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_ulonglong)]),

@@ -335,6 +335,20 @@ __global__ void fnv_kernel(const unsigned long long* __restrict__ ptrs, const ui
 
 extern "C" {
 
+static int run_batch(int device, int kind, const sqoa_hip_job* jobs, int n, sqoa_hip_result* results) {
+    if (n < 0 || (n > 0 && (!jobs || !results))) return fail(SQOA_HIP_EINVAL, "sqoa_hip_*_batch: bad arguments");
+    if (n == 0) return 0;
+    sqoa_hip_plan* p = nullptr;
+    int rc = sqoa_hip_plan_create(device, kind, jobs, n, &p);
+    if (rc) return rc;
+    rc = sqoa_hip_plan_launch(p, nullptr);
+    if (!rc) rc = sqoa_hip_plan_results(p, results, n);
+    sqoa_hip_plan_destroy(p);
+    return rc;
+}
+int sqoa_hip_encode_batch(int device, const sqoa_hip_job* jobs, int n, sqoa_hip_result* results) { return run_batch(device, SQOA_HIP_ENCODE, jobs, n, results); }
+int sqoa_hip_decode_batch(int device, const sqoa_hip_job* jobs, int n, sqoa_hip_result* results) { return run_batch(device, SQOA_HIP_DECODE, jobs, n, results); }
+
 int sqoa_hip_synth(int device, unsigned long long dst, size_t stride, unsigned w, unsigned h, unsigned channels,
                    int cls, unsigned seed, unsigned img0, int n) {
     if (!dst || !w || !h || (channels != 3 && channels != 4) || cls < 0 || cls > 2 || n < 0 || (size_t)w * h > 0xffffffffu)

@@ -326,3 +326,38 @@ def test_padded_batch_arena_matches_contiguous_batch(sq, orc):
         dec.launch()
         assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, flat)
         assert (gout == 0xA5).all() and (guard == 0xA5).all()
+
+
+def test_one_shot_batch_entry_points(sq, orc):
+    """sqoa_hip_encode_batch / sqoa_hip_decode_batch (array of descriptors and device buffers in, slots
+    and lengths out) give what the plan API gives: byte-identical streams, exact round trip, refused jobs flagged."""
+    import ctypes as C
+    import torch
+    from seqoia_amd._lib import Job, Result, load
+
+    lib, o = load(), orc.best()
+    shapes = [(64, 64, 4, "icon", 0), (200, 150, 3, "photo", 1), (333, 77, 4, "mixed", 0), (0, 4, 4, "mixed", 0)]
+    raws, pix, slots, jobs = [], [], [], (Job * len(shapes))()
+    for k, (w, h, c, cls, mode) in enumerate(shapes):
+        raw = orc.synth(max(w, 1), h, c, cls, 5, k)
+        d = sq.Desc(w, h, c, 0, mode)
+        t = torch.from_numpy(raw).cuda()
+        sl = torch.zeros(int(sq.encode_bound(sq.Desc(max(w, 1), h, c, 0, mode))), dtype=torch.uint8, device="cuda")
+        raws.append(raw); pix.append(t); slots.append(sl)
+        jobs[k] = Job(t.data_ptr(), sl.data_ptr(), 0, sl.numel(), d, 0)
+    res = (Result * len(shapes))()
+    assert lib.sqoa_hip_encode_batch(0, jobs, len(shapes), res) == 0
+    assert res[3].status == 1 and res[3].len == 0  # width 0: refused like sqoa_encode (seqoia.h:465-473)
+    outs, djobs = [], (Job * 3)()
+    for k, (w, h, c, cls, mode) in enumerate(shapes[:3]):
+        assert res[k].status == 0
+        assert bytes(slots[k][: res[k].len].cpu().numpy()) == o.encode(raws[k], w, h, c, mode), k
+        out = torch.zeros(w * h * c, dtype=torch.uint8, device="cuda")
+        outs.append(out)
+        djobs[k] = Job(slots[k].data_ptr(), out.data_ptr(), res[k].len, out.numel(), sq.Desc(0, 0, c, 0, 0), 0)
+    dres = (Result * 3)()
+    assert lib.sqoa_hip_decode_batch(0, djobs, 3, dres) == 0
+    for k, (w, h, c, cls, mode) in enumerate(shapes[:3]):
+        assert dres[k].status == 0 and dres[k].len == w * h * c and dres[k].desc.qoi_compat == mode
+        assert torch.equal(outs[k].cpu(), torch.from_numpy(raws[k])), k
+    assert lib.sqoa_hip_encode_batch(0, None, 0, None) == 0 and lib.sqoa_hip_encode_batch(0, None, 1, None) != 0
