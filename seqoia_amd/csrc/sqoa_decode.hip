@@ -233,8 +233,11 @@ SQOA_DEV bool qd_wait(uint32_t* flag, uint32_t want, uint32_t* stop, uint32_t& b
 // Front wave: stage, parse, decode ops into stream-order records (everything that does not depend on pixel values).
 SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& bad) {
     gcptr8 src = (gcptr8)job.src;
-    const uint32_t size = job.src_size;
-    const uint32_t p0 = kHeader;                // first chunk byte (QOI: right after the header, seqoia.h:705)
+    // (any byte address: offsets are relative to the dword-aligned address at or in front of the stream)
+    const uint32_t soff = (uint32_t)(job.src & 3ull);
+    src -= soff;
+    const uint32_t size = job.src_size + soff;
+    const uint32_t p0 = kHeader + soff;         // first chunk byte (QOI: right after the header, seqoia.h:705)
     const uint32_t chunks_len = size - 8;       // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
     const Hdr h = parse_header((gcptr8)job.src, res, threadIdx.x == 0);
     if (!h.ok) { if (threadIdx.x == 0) res->status = SQOA_HIP_ST_BADARG; return; }
     const uint32_t oc = job.desc.channels ? job.desc.channels : (h.channels < 3 ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u);
-    const bool wave_ok = h.qoi && h.channels >= 3 && oc >= 3 && (job.src & 3ull) == 0 &&
+    const bool wave_ok = h.qoi && h.channels >= 3 && oc >= 3 &&
                          (unsigned long long)h.width * h.height * oc <= job.dst_cap;
     if (!wave_ok) {
         if (threadIdx.x == 0) decode_exact(job, h, res, &L.rec_v[0][0]);  // (the record buffers are free: 128 dwords of colour index)

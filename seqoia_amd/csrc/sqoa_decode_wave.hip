@@ -130,7 +130,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         else {
             const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
             if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
-            else if (hc < 3 || q || oc < 3 || (job.src & 3ull)) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }
+            else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }
         }
         s_path = path;
     }
@@ -162,8 +162,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const uint32_t hc = src[12];
     const uint32_t N = bcast_first(hw * hh);
     const int oc = (int)bcast_first(job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u));
-    const uint32_t p0 = kHeader + 1;            // first chunk byte (SQOA: after the start byte, seqoia.h:705)
-    const uint32_t chunks_len = size - 8;       // seqoia.h:721
+    // Streams packed back to back (sqoa_hip_pack) start at any byte address: all stream offsets below are relative to the
+    // dword-aligned address at or in front of the stream; the `soff` bytes in front of it are loaded but never looked at.
+    const uint32_t soff = (uint32_t)(job.src & 3ull);
+    gcptr8 srca = src - soff;
+    const uint32_t size_a = size + soff;
+    const uint32_t p0 = kHeader + 1 + soff;     // first chunk byte (SQOA: after the start byte, seqoia.h:705)
+    const uint32_t chunks_len = size_a - 8;     // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
     uint32_t bad = 0;
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[DEC_NLD]) {
         const uint32_t gs = p0 + c * DEC_CHUNK;
         const uint32_t d0 = gs >> 2;
-        if ((d0 + DEC_LDS_DW) * 4u <= size) {
-            gcptr32 p = (gcptr32)src + d0;
+        if ((d0 + DEC_LDS_DW) * 4u <= size_a) {
+            gcptr32 p = (gcptr32)srca + d0;
 #pragma unroll
             for (int k = 0; k < DEC_NLD - 1; ++k) r[k] = p[lane + 64 * k];
             r[DEC_NLD - 1] = p[64 * (DEC_NLD - 1) + (lane & 7)];
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #pragma unroll
             for (int k = 0; k < DEC_NLD; ++k) {
                 const uint32_t d = d0 + lane + 64 * k;
-                r[k] = (k < DEC_NLD - 1 || lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) && d * 4u < size ? ((gcptr32)src)[d] : 0u;
+                r[k] = (k < DEC_NLD - 1 || lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) && d * 4u < size_a ? ((gcptr32)srca)[d] : 0u;
             }
         }
     };

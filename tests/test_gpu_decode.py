@@ -368,3 +368,33 @@ def test_qoi_long_random_streams_match_oracle(sq, orc):
             assert res["status"][i] == 0 and res["qoi_compat"][i] == 1, (oc, i)
             assert out[i].tobytes() == want.tobytes(), (oc, i)
         dec.close()
+
+
+def test_decode_from_packed_blob_at_any_byte_address(sq, orc):
+    """Streams compacted by sqoa_hip_pack sit back to back, i.e. at arbitrary byte addresses; the wave-parallel decoders
+    (SQOA and QOI-compat) take them where they are: exact pixels for every alignment of the stream start."""
+    import torch
+    from seqoia_amd.api import Plan, DECODE, Job
+
+    shapes = [(96, 40, 4, "mixed", 0), (64, 64, 4, "icon", 1), (333, 21, 3, "photo", 0), (120, 50, 3, "mixed", 1), (257, 9, 4, "mixed", 0),
+              (80, 80, 4, "photo", 1), (33, 33, 3, "icon", 0), (512, 6, 4, "mixed", 1)]
+    images, raws = [], []
+    for k, (w, h, c, cls, mode) in enumerate(shapes):
+        raw = orc.synth(w, h, c, cls, 8, k)
+        raws.append(raw)
+        images.append((torch.from_numpy(raw).cuda(), sq.Desc(w, h, c, 0, mode)))
+    enc = sq.EncodeList(images)
+    enc.launch()
+    blob, offsets = enc.pack()
+    off = offsets.cpu().numpy()
+    assert len({int(o) % 4 for o in off[:-1]}) > 1  # the blob really holds unaligned streams
+    outs = [torch.zeros(w * h * c, dtype=torch.uint8, device="cuda") for (w, h, c, _, _) in shapes]
+    jobs = [Job(blob.data_ptr() + int(off[k]), outs[k].data_ptr(), int(off[k + 1] - off[k]), outs[k].numel(), sq.Desc(0, 0, shapes[k][2], 0, 0), 0)
+            for k in range(len(shapes))]
+    dec = Plan(DECODE, jobs, 0)
+    dec.launch()
+    res = dec.results()
+    for k, (w, h, c, cls, mode) in enumerate(shapes):
+        assert res["status"][k] == 0 and res["len"][k] == w * h * c and res["qoi_compat"][k] == mode, k
+        assert bytes(outs[k].cpu().numpy()) == raws[k].tobytes(), k
+    dec.close(); enc.close()
