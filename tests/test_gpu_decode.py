@@ -388,7 +388,14 @@ def test_decode_from_packed_blob_at_any_byte_address(sq, orc):
     blob, offsets = enc.pack()
     off = offsets.cpu().numpy()
     assert len({int(o) % 4 for o in off[:-1]}) > 1  # the blob really holds unaligned streams
-    outs = [torch.zeros(w * h * c, dtype=torch.uint8, device="cuda") for (w, h, c, _, _) in shapes]
+    # ... and the pixel outputs sit at odd addresses of one arena as well
+    sizes = [w * h * c for (w, h, c, _, _) in shapes]
+    arena = torch.zeros(sum(sizes) + 8 * len(sizes) + 8, dtype=torch.uint8, device="cuda")
+    outs, at = [], 0
+    for k, n in enumerate(sizes):
+        at = (at + 7) // 8 * 8 + (k % 4)
+        outs.append(arena[at:at + n]); at += n
+    assert {o.data_ptr() % 4 for o in outs} == {0, 1, 2, 3}
     jobs = [Job(blob.data_ptr() + int(off[k]), outs[k].data_ptr(), int(off[k + 1] - off[k]), outs[k].numel(), sq.Desc(0, 0, shapes[k][2], 0, 0), 0)
             for k in range(len(shapes))]
     dec = Plan(DECODE, jobs, 0)
