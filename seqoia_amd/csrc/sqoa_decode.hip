@@ -3,7 +3,7 @@
 // Replaces the reference decoder loop (seqoia.h:722-806) and its header handling (seqoia.h:672-707) for every
 // stream sqoa_decode_wave.hip declines (SQOA_HIP_ST_SLOWPATH).  One workgroup of two waves per image:
 //
-//   * decode_qoi (QOI-compat colour streams, 3/4 output channels).  QOI_OP_INDEX makes every later pixel depend on
+//   * the record pipeline (QOI-compat colour streams; SQOA mono streams; any output channel count).  QOI_OP_INDEX makes every later pixel depend on
 //     the VALUES of all earlier ones (the slot is a hash of the value, seqoia.h:785-787), so pixel values cannot be
 //     scanned like SQOA's.  Everything else still runs across the wave, 512 stream bytes at a time: cooperative
 //     staging in LDS, the parser as a scan of transition functions, every lane decoding the ops that start in its 8
@@ -13,8 +13,8 @@
 //     pixels and expands the runs.  The two waves are coupled by double-buffered record arrays in LDS.  Parallelism
 //     across images comes from the batch: one workgroup per image, thousands of workgroups.
 //   * decode_exact: the complete op set exactly as the reference parses it, including the crafted-input cases
-//     (SQOA_OP_REF with the SQOA_NEXT cursor quirk seqoia.h:418/:729-738, mono streams with a 128-entry index,
-//     1/2-channel output, exhausted streams), one lane per image.  It is the correctness net for whatever the two
+//     (SQOA_OP_REF with the SQOA_NEXT cursor quirk seqoia.h:418/:729-738, mono streams in QOI framing with their
+//     128-entry index, SQOA colour streams to 1/2 channels, exhausted streams), one lane per image.  It is the correctness net for whatever the two
 //     wave-parallel decoders decline.
 #include <type_traits>
 
@@ -231,13 +231,13 @@ SQOA_DEV bool qd_wait(uint32_t* flag, uint32_t want, uint32_t* stop, uint32_t& b
 }
 
 // Front wave: stage, parse, decode ops into stream-order records (everything that does not depend on pixel values).
-SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& bad) {
+SQOA_DEV void qoi_front(const sqoa_hip_job& job, bool mono, QoiLds& L, int lane, uint32_t& bad) {
     gcptr8 src = (gcptr8)job.src;
     // (any byte address: offsets are relative to the dword-aligned address at or in front of the stream)
     const uint32_t soff = (uint32_t)(job.src & 3ull);
     src -= soff;
     const uint32_t size = job.src_size + soff;
-    const uint32_t p0 = kHeader + soff;         // first chunk byte (QOI: right after the header, seqoia.h:705)
+    const uint32_t p0 = kHeader + (mono ? 1u : 0u) + soff;  // first chunk byte (QOI: right after the header; SQOA: after the start byte, seqoia.h:705)
     const uint32_t chunks_len = size - 8;       // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
@@ -284,6 +284,7 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& 
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)QD_LB : 0u);
         uint32_t rv[QD_LB], rm[QD_LB];
         uint32_t nops = 0, iters = QD_LB;
+        bool ref = false;
 #pragma unroll
         for (int i = 0; i < QD_LB; ++i) {
             const bool act = pos < nlive;
@@ -291,7 +292,18 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& 
             const unsigned long long q = lds_read8(L.bytes, loff + (pos < (uint32_t)QD_LB ? pos : (uint32_t)QD_LB));
             const uint32_t b0 = (uint32_t)q & 0xffu, b1 = ((uint32_t)q >> 8) & 0xffu;
             uint32_t v = 0, m = 0, cnt = 1, len = 1;
-            if (b0 >= 0xfeu) {                       // seqoia.h:740-752
+            if (mono) {
+                // SQOA mono / mono+alpha streams: only g and a exist (r = b = 0 throughout), no ALPHA suffix, no colour index
+                if (b0 >= 0xfeu) {                   // seqoia.h:740-752 with col == 1: fe g / ff g a
+                    v = (b1 << 8) | (b0 == 0xffu ? (uint32_t)(q >> 16) << 24 : 0u);
+                    m = b0 == 0xffu ? 4u : 2u;
+                    len = b0 - 0xfcu;
+                } else if (b0 < 0x60u) {             // SQOA_OP_REF (seqoia.h:729-738): the exact decoder takes the image
+                    if (act) ref = true;
+                } else if ((b0 & 0xc0u) == 0x80u) {  // seqoia.h:761-764: one byte
+                    v = (((b0 & 0x3fu) - 32u) & 0xffu) << 8;
+                } else cnt = b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u;  // seqoia.h:770-775
+            } else if (b0 >= 0xfeu) {                // seqoia.h:740-752
                 v = (uint32_t)(q >> 8) & (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu);
                 m = b0 == 0xffu ? 4u : 2u;
                 len = b0 - 0xfau;
@@ -305,11 +317,15 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& 
                 len = 2;
             } else cnt = (b0 & 0x3fu) + 1u;          // seqoia.h:773-775
             rv[i] = v;
-            rm[i] = act ? (m | cnt << 9) : 0u;
+            rm[i] = act ? (m | cnt << (mono ? 3 : 9)) : 0u;  // QOI: slot in bits 3-8, runs <= 62; mono: no slot, runs <= 512
             nops += act ? 1u : 0u;
             pos += act ? len : 0u;
         }
 
+        if (__ballot(ref) != 0ull) {  // hand the whole image to decode_exact
+            if (lane == 0) __hip_atomic_store(&L.stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
         // ---- records in stream order, handed to the back wave ----
         const uint32_t oinc = wave_incl_scan(nops);
         const uint32_t T = bcast_lane(oinc, 63);
@@ -318,7 +334,7 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& 
 #pragma unroll
         for (int i = 0; i < QD_LB; ++i) {
             if ((uint32_t)i >= iters) break;
-            if (rm[i] >> 9) { L.rec_v[buf][obase + i] = rv[i]; L.rec_m[buf][obase + i] = (uint16_t)rm[i]; }
+            if (rm[i] >> 3) { L.rec_v[buf][obase + i] = rv[i]; L.rec_m[buf][obase + i] = (uint16_t)rm[i]; }
         }
         if (lane == 0) L.nrec[buf] = T;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -328,12 +344,20 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, QoiLds& L, int lane, uint32_t& 
 }
 
 // Back wave: the recurrence of seqoia.h:740-787 over the records, 64 ops (one per lane) at a time, and the pixels.
-SQOA_DEV void qoi_back(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* res, QoiLds& L, int lane, uint32_t& bad) {
+// bytes a pixel is stored as (seqoia.h:790-805): colour r g b [a] / g [a]; mono g g g [a] / g [a]
+SQOA_DEV uint32_t out_px(uint32_t px, bool mono) { return mono ? (((px >> 8) & 0xffu) * 0x010101u) | (px & 0xff000000u) : px; }
+SQOA_DEV void put_small(gptr8 out, uint32_t P, int oc, uint32_t px) {  // 1 / 2 output channels: g [a]
+    gptr8 o = out + (size_t)P * (unsigned)oc;
+    o[0] = (uint8_t)(px >> 8);
+    if (oc == 2) o[1] = (uint8_t)(px >> 24);
+}
+
+SQOA_DEV void qoi_back(const sqoa_hip_job& job, const Hdr& h, bool mono, sqoa_hip_result* res, QoiLds& L, int lane, uint32_t& bad) {
     gptr8 out = (gptr8)job.dst;
     const uint32_t size = job.src_size;
     const uint32_t N = h.width * h.height;
-    const int oc = (int)(job.desc.channels ? job.desc.channels : 3u + ((h.channels & 1u) ? 0u : 1u));
-    const uint32_t p0 = kHeader, chunks_len = size - 8;
+    const int oc = (int)(job.desc.channels ? job.desc.channels : (mono ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u));
+    const uint32_t p0 = kHeader + (mono ? 1u : 0u), chunks_len = size - 8;
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QD_CHUNK - 1) / QD_CHUNK : 1;
     const bool dw_out = oc == 4 && (job.dst & 3ull) == 0;
@@ -390,35 +414,40 @@ SQOA_DEV void qoi_back(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* r
                 if (s0 >= ng) break;
             }
             // ---- pixels of these 64 ops: literal ops lane-local, runs by the whole wave (seqoia.h:723-725, :790-805) ----
-            const uint32_t cnt = m >> 9;
+            const uint32_t cnt = mono ? m >> 3 : m >> 9;
             const uint32_t pinc = wave_incl_scan(cnt);
+            const uint32_t pxo = out_px(resv, mono);
             const uint32_t P = pos_in + pinc - cnt;
             const bool any_long = __ballot(cnt > 2u) != 0ull;
             if (dw_out) {
-                if (cnt >= 1u && cnt <= 2u && P < N) ((gptr32)out)[P] = resv;
-                if (cnt == 2u && P + 1u < N) ((gptr32)out)[P + 1u] = resv;
-            } else {
+                if (cnt >= 1u && cnt <= 2u && P < N) ((gptr32)out)[P] = pxo;
+                if (cnt == 2u && P + 1u < N) ((gptr32)out)[P + 1u] = pxo;
+            } else if (oc >= 3) {
                 for (uint32_t k = 0; k < cnt && k < 2u && cnt <= 2u && P + k < N; ++k) {
                     gptr8 o = out + (size_t)(P + k) * (unsigned)oc;
-                    o[0] = (uint8_t)resv; o[1] = (uint8_t)(resv >> 8); o[2] = (uint8_t)(resv >> 16);
-                    if (oc == 4) o[3] = (uint8_t)(resv >> 24);
+                    o[0] = (uint8_t)pxo; o[1] = (uint8_t)(pxo >> 8); o[2] = (uint8_t)(pxo >> 16);
+                    if (oc == 4) o[3] = (uint8_t)(pxo >> 24);
                 }
+            } else {
+                for (uint32_t k = 0; k < cnt && k < 2u && cnt <= 2u && P + k < N; ++k) put_small(out, P + k, oc, resv);
             }
             if (any_long) {
                 unsigned long long runs = __ballot(cnt > 2u && P < N);
                 while (runs) {
                     const int l = __builtin_ctzll(runs);
                     runs &= runs - 1ull;
-                    const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(resv, l);
+                    const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(pxo, l), rraw = bcast_lane(resv, l);
                     uint32_t rc = bcast_lane(cnt, l);
                     if (rp + rc > N) rc = N - rp;
                     if (dw_out) fill_pixels<4>(out, rp, rc, rvv, lane);
                     else if (oc == 3) fill_pixels<3>(out, rp, rc, rvv, lane);
-                    else
+                    else if (oc == 4)
                         for (uint32_t k = lane; k < rc; k += 64) {
                             gptr8 o = out + (size_t)(rp + k) * 4;
                             o[0] = (uint8_t)rvv; o[1] = (uint8_t)(rvv >> 8); o[2] = (uint8_t)(rvv >> 16); o[3] = (uint8_t)(rvv >> 24);
                         }
+                    else
+                        for (uint32_t k = lane; k < rc; k += 64) put_small(out, rp + k, oc, rraw);
                 }
             }
             const uint32_t ptot = bcast_lane(pinc, 63);
@@ -427,16 +456,20 @@ SQOA_DEV void qoi_back(const sqoa_hip_job& job, const Hdr& h, sqoa_hip_result* r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&L.freed[buf], c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (lane == 0) __hip_atomic_store(&L.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_max(&L.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // stream exhausted: the last pixel repeats (seqoia.h:726)
-    if (pos_in < N && !bad) {
-        if (dw_out) fill_pixels<4>(out, pos_in, N - pos_in, pxv, lane);
-        else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, pxv, lane);
-        else
+    const bool aborted = bcast_first(__hip_atomic_load(&L.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 2u;
+    if (pos_in < N && !bad && !aborted) {
+        const uint32_t pxo = out_px(pxv, mono);
+        if (dw_out) fill_pixels<4>(out, pos_in, N - pos_in, pxo, lane);
+        else if (oc == 3) fill_pixels<3>(out, pos_in, N - pos_in, pxo, lane);
+        else if (oc == 4)
             for (uint32_t k = pos_in + lane; k < N; k += 64) {
                 gptr8 o = out + (size_t)k * 4;
-                o[0] = (uint8_t)pxv; o[1] = (uint8_t)(pxv >> 8); o[2] = (uint8_t)(pxv >> 16); o[3] = (uint8_t)(pxv >> 24);
+                o[0] = (uint8_t)pxo; o[1] = (uint8_t)(pxo >> 8); o[2] = (uint8_t)(pxo >> 16); o[3] = (uint8_t)(pxo >> 24);
             }
+        else
+            for (uint32_t k = pos_in + lane; k < N; k += 64) put_small(out, k, oc, pxv);
     }
     if (lane == 0) res->len = (int)(N * (uint32_t)oc);
 }
@@ -457,23 +490,30 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
     const Hdr h = parse_header((gcptr8)job.src, res, threadIdx.x == 0);
     if (!h.ok) { if (threadIdx.x == 0) res->status = SQOA_HIP_ST_BADARG; return; }
     const uint32_t oc = job.desc.channels ? job.desc.channels : (h.channels < 3 ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u);
-    const bool wave_ok = h.qoi && h.channels >= 3 && oc >= 3 &&
-                         (unsigned long long)h.width * h.height * oc <= job.dst_cap;
+    // what the record pipeline takes: QOI-compat colour streams and SQOA mono streams, any output channel count
+    const bool mono = !h.qoi && h.channels < 3;
+    const bool wave_ok = ((h.qoi && h.channels >= 3) || mono) && (unsigned long long)h.width * h.height * oc <= job.dst_cap;
     if (!wave_ok) {
         if (threadIdx.x == 0) decode_exact(job, h, res, &L.rec_v[0][0]);  // (the record buffers are free: 128 dwords of colour index)
         return;
     }
-    // QOI-compat colour stream: wave 0 turns bytes into op records, wave 1 turns records into pixels (seqoia.h:722-806)
+    // wave 0 turns bytes into op records, wave 1 turns records into pixels (seqoia.h:722-806)
     if (threadIdx.x < 64) { L.stamp[lane] = 0; if (lane < 2) { L.ready[lane] = 0; L.freed[lane] = 0; L.nrec[lane] = 0; } if (lane == 0) L.stop = 0; }
-    for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += 128) {  // QOI op lengths: fe 4, ff 5, 10xxxxxx 2, everything else 1
-        const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
+    for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += 128) {  // op lengths -- QOI: fe 4, ff 5, 10xxxxxx 2; SQOA mono: fe 2, ff 3; all others 1
+        const uint32_t len = mono ? (b0 >= 0xfeu ? b0 - 0xfcu : 1u) : (b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u));
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
         L.ftab[b0] = opn | opn << 8 | 0x02000000u;
     }
     __syncthreads();
     uint32_t bad = 0;
-    if (w == 0) qoi_front(job, L, lane, bad);
-    else qoi_back(job, h, res, L, lane, bad);
+    if (w == 0) qoi_front(job, mono, L, lane, bad);
+    else qoi_back(job, h, mono, res, L, lane, bad);
+    __syncthreads();
+    if (L.stop == 2u) {  // a REF op in a mono stream: redo the image exactly
+        __syncthreads();
+        if (threadIdx.x == 0) decode_exact(job, h, res, &L.rec_v[0][0]);
+        return;
+    }
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 }
 

@@ -405,3 +405,35 @@ def test_decode_from_packed_blob_at_any_byte_address(sq, orc):
         assert res["status"][k] == 0 and res["len"][k] == w * h * c and res["qoi_compat"][k] == mode, k
         assert bytes(outs[k].cpu().numpy()) == raws[k].tobytes(), k
     dec.close(); enc.close()
+
+
+def test_mono_streams_all_channel_args(sq, orc):
+    """MONO / MONO+ALPHA streams (seqoia.h:477-486, :746-748, :795-801) over many 512-byte steps through the record
+    pipeline of decode_fallback_kernel, for every `channels` argument; and QOI-compat colour streams to 1 and 2 channels."""
+    import torch
+    from seqoia_amd.api import Plan, DECODE, Job
+
+    o = orc.best()
+    rng = np.random.default_rng(5)
+    streams = []
+    for k, (w, h, c) in enumerate([(300, 200, 1), (257, 129, 2), (640, 48, 1), (64, 64, 2)]):
+        n = w * h * c
+        raw = ((np.arange(n) // (7 + k)) + rng.integers(0, 2, n) * rng.integers(0, 60, n)).astype(np.uint8)
+        raw[n // 3: n // 3 + 3000 * c] = 17          # a long run (BIGRUN)
+        streams.append((o.encode(raw, w, h, c, 0), w, h))
+    for k, (w, h, c) in enumerate([(200, 100, 4), (96, 96, 3)]):  # QOI-compat colour -> g / g a
+        streams.append((o.encode(orc.synth(w, h, c, "mixed", 2, k), w, h, c, 1), w, h))
+    blob = torch.from_numpy(np.frombuffer(b"".join(s for s, _, _ in streams), dtype=np.uint8).copy()).cuda()
+    offs = np.cumsum([0] + [len(s) for s, _, _ in streams])
+    for arg in (0, 1, 2, 3, 4):
+        wants = [o.decode(s, arg) for s, _, _ in streams]
+        outs = [torch.zeros(len(wt[0]), dtype=torch.uint8, device="cuda") for wt in wants]
+        jobs = [Job(blob.data_ptr() + int(offs[i]), outs[i].data_ptr(), len(streams[i][0]), outs[i].numel(), sq.Desc(0, 0, arg, 0, 0), 0)
+                for i in range(len(streams))]
+        dec = Plan(DECODE, jobs, 0)
+        dec.launch()
+        res = dec.results()
+        for i, (want, desc) in enumerate(wants):
+            assert res["status"][i] == 0 and res["len"][i] == len(want), (arg, i)
+            assert bytes(outs[i].cpu().numpy()) == want.tobytes(), (arg, i)
+        dec.close()
