@@ -440,8 +440,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             gcptr8 p = src + (size_t)base * 4;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
-            pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4, 0u);
-            pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4, 0u);
+            if ((job.src & 3ull) == 0) {  // dword-aligned pixels: one scalar load each
+                pb = NbrPx{*(kcptr32)(job.src + (unsigned long long)base * 4 - 4), 0u, 0u, 0u};
+                pa = NbrPx{*(kcptr32)(job.src + (unsigned long long)base * 4 + ENC_SUB * 4), 0u, 0u, 0u};
+            } else {
+                pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4, 0u);
+                pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4, 0u);
+            }
         } else if (base > 0 && base + ENC_SUB < N && ch == 3) {
             gcptr8 p = src + (size_t)base * 3;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
