@@ -42,12 +42,6 @@ constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk 
 constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
 constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 
-struct DecShared {
-    unsigned long long parse[2];  // per parity: tag<<32 | exit parser state
-    unsigned long long pos[1];    // tag<<32 | pixel position leaving the chunk
-    unsigned long long px[1];     // tag<<32 | pixel value leaving the chunk
-};
-
 SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const uint32_t* abort_flag, uint32_t& val, uint32_t& bad) {
     for (uint32_t spin = 0; spin < DEC_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
