@@ -361,3 +361,27 @@ def test_one_shot_batch_entry_points(sq, orc):
         assert dres[k].status == 0 and dres[k].len == w * h * c and dres[k].desc.qoi_compat == mode
         assert torch.equal(outs[k].cpu(), torch.from_numpy(raws[k])), k
     assert lib.sqoa_hip_encode_batch(0, None, 0, None) == 0 and lib.sqoa_hip_encode_batch(0, None, 1, None) != 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_repeated_launches_are_bit_identical(sq, orc, mode):
+    """Race detector for the wave-to-wave chains (run length, output position, colour index): the same plan launched over
+    and over must write the same bytes every time, and decode back to the pixels every time."""
+    import torch
+
+    n, s = 128, 256
+    px = torch.empty((n, s, s, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", 7, 0)
+    enc = sq.EncodePlan(px, qoi_compat=mode)
+    enc.out.zero_(); torch.cuda.synchronize()
+    enc.launch(); res0 = enc.results()
+    ref = enc.out.clone()
+    assert bytes(ref[0, : int(res0["len"][0])].cpu().numpy()) == orc.best().encode(orc.synth(s, s, 4, "mixed", 7, 0), s, s, 4, mode)
+    dec = sq.DecodePlan(ref, res0["len"], s, s, 4)
+    for _ in range(12):
+        enc.out.zero_(); dec.out.zero_(); torch.cuda.synchronize()
+        enc.launch(); res = enc.results()
+        assert (res["len"] == res0["len"]).all() and torch.equal(enc.out, ref)
+        dec.launch()
+        assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, px)
+    dec.close(); enc.close()
