@@ -486,8 +486,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // One sub-tile.  SW (compile time) = the SWAR path: colour image, sub-tile fully inside the image.  The loop over the
     // full sub-tiles of a colour image is instantiated with SW = true only, so the generic one-row-per-step code (mono
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
-    auto body = [&](auto sw_tag, uint32_t j, bool more) {
+    auto body = [&](auto sw_tag, auto mid_tag, uint32_t j, bool more) {
         constexpr bool SW = decltype(sw_tag)::value;
+        constexpr bool MID = decltype(mid_tag)::value;  // a full sub-tile follows: no end-of-image cases in this instance
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
         // cur[] was read from the landing buffer at the end of the previous sub-tile and those reads have long returned
@@ -499,8 +500,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         const uint32_t base = j * ENC_SUB;
         const uint32_t pb = cur_pb;
         const uint32_t pa = cur_pa;
-        const bool has_after = base + ENC_SUB < N;
-        const bool last_sub = j == nsub - 1;
+        const bool has_after = MID ? true : base + ENC_SUB < N;
+        const bool last_sub = MID ? false : j == nsub - 1;
 
         // ---- pre-pass: equality masks (from the SWAR classification on the fast path), local run aggregate ----
         unsigned long long E[ENC_S];
@@ -729,29 +730,31 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                        thr3 = (uint32_t)((unsigned long long)nfull * SQOA_PRIO_T3 >> 6);
         uint32_t thr = thr1, q = 0;
         __builtin_amdgcn_s_setprio(3);
-        for (; j < nfull; j += W) {
+        const uint32_t nmid = nfull ? nfull - 1u : 0u;  // full sub-tiles that have a full sub-tile behind them
+        for (; j < nmid; j += W) {
             if (j >= thr) {
                 ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
                 if (q == 1) __builtin_amdgcn_s_setprio(2);
                 else if (q == 2) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            body(std::true_type{}, j, j + W < nfull);
+            body(std::true_type{}, std::true_type{}, j, j + W < nfull);
         }
+        for (; j < nfull; j += W) body(std::true_type{}, std::false_type{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
-        for (; j < nfull; j += W) body(std::true_type{}, j, j + W < nfull);
+        for (; j < nfull; j += W) body(std::true_type{}, std::false_type{}, j, j + W < nfull);
 #endif
         if (nsub > nfull && nfull % W == (uint32_t)w) {  // the image's partial last sub-tile
             NbrPx b_, a_;
             fetch(nfull, b_, a_, cur_raw3);
             take(cur, cur_raw3);
             cur_pb = b_.value(); cur_pa = a_.value();
-            body(std::false_type{}, nfull, false);
+            body(std::false_type{}, std::false_type{}, nfull, false);
         }
     } else {
         uint32_t j = w;
         if (j < nsub) { NbrPx b_, a_; fetch(j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
-        for (; j < nsub; j += W) body(std::false_type{}, j, j + W < nsub);
+        for (; j < nsub; j += W) body(std::false_type{}, std::false_type{}, j, j + W < nsub);
     }
     if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);
 #ifdef SQOA_TRACE
