@@ -488,7 +488,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
     auto body = [&](auto sw_tag, auto mid_tag, uint32_t j, bool more) {
         constexpr bool SW = decltype(sw_tag)::value;
-        constexpr bool MID = decltype(mid_tag)::value;  // a full sub-tile follows: no end-of-image cases in this instance
+        constexpr bool MID = decltype(mid_tag)::value;  // j > 0, full sub-tiles follow, `more` is true: no edge cases in this instance
+        if (MID) { __builtin_assume(j > 0); __builtin_assume(more); }
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
         // cur[] was read from the landing buffer at the end of the previous sub-tile and those reads have long returned
@@ -730,7 +731,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                        thr3 = (uint32_t)((unsigned long long)nfull * SQOA_PRIO_T3 >> 6);
         uint32_t thr = thr1, q = 0;
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t nmid = nfull ? nfull - 1u : 0u;  // full sub-tiles that have a full sub-tile behind them
+        // MID instance of the body: not the wave's first sub-tile (j > 0), a full sub-tile behind it, and another one of this
+        // wave's to prefetch (j + W < nfull - 1 ... all three known at compile time); the few others take the general instance
+        if (j < nfull) { body(std::true_type{}, std::false_type{}, j, j + W < nfull); j += W; }
+        const uint32_t nmid = nfull > (uint32_t)W ? nfull - (uint32_t)W : 0u;
         for (; j < nmid; j += W) {
             if (j >= thr) {
                 ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 else if (q == 2) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            body(std::true_type{}, std::true_type{}, j, j + W < nfull);
+            body(std::true_type{}, std::true_type{}, j, true);
         }
         for (; j < nfull; j += W) body(std::true_type{}, std::false_type{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
