@@ -433,10 +433,14 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
     // (64 VGPRs).  The two neighbour pixels are wave-uniform and come through the scalar cache.  Sub-tiles at the image edges,
     // and 1- / 2-byte pixels, are loaded the plain way and stored to the same buffer as canonical dwords.
-    auto fetch = [&](uint32_t j, NbrPx& pb, NbrPx& pa, bool& raw3) {
+    // K (compile time): 0 = anything; 1 = an interior sub-tile (full sub-tiles on both sides) of a 3- or 4-byte image;
+    // 2 = an interior sub-tile of a 4-byte image.  The hot loop is instantiated with 1 or 2.
+    auto fetch = [&](auto kind_tag, uint32_t j, NbrPx& pb, NbrPx& pa, bool& raw3) {
+        constexpr int K = decltype(kind_tag)::value;
         const uint32_t base = j * ENC_SUB;
+        const bool interior = K ? true : (base > 0 && base + ENC_SUB < N);
         raw3 = false;
-        if (base > 0 && base + ENC_SUB < N && ch == 4) {
+        if (interior && (K == 2 || ch == 4)) {
             gcptr8 p = src + (size_t)base * 4;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
@@ -447,14 +451,14 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 pb = sload_px(job.src + (unsigned long long)base * 4 - 4, 4, 0u);
                 pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4, 0u);
             }
-        } else if (base > 0 && base + ENC_SUB < N && ch == 3) {
+        } else if (K != 2 && interior && (K == 1 || ch == 3)) {
             gcptr8 p = src + (size_t)base * 3;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             if (lane < 32) __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
             pb = sload_px(job.src + (unsigned long long)base * 3 - 3, 3, 0xff000000u);
             pa = sload_px(job.src + (unsigned long long)base * 3 + ENC_SUB * 3, 3, 0xff000000u);
             raw3 = true;
-        } else {
+        } else if (K == 0) {
             uint32_t px[ENC_S];
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) {
@@ -488,14 +492,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
     auto body = [&](auto sw_tag, auto mid_tag, uint32_t j, bool more) {
         constexpr bool SW = decltype(sw_tag)::value;
-        constexpr bool MID = decltype(mid_tag)::value;  // j > 0, full sub-tiles follow, `more` is true: no edge cases in this instance
+        constexpr int KIND = decltype(mid_tag)::value;   // 0: general; 1 / 2: hot-loop instance (2: 4-byte pixels known)
+        constexpr bool MID = KIND != 0;                   // j > 0, full sub-tiles follow, `more` is true: no edge cases in this instance
         if (MID) { __builtin_assume(j > 0); __builtin_assume(more); }
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
         // cur[] was read from the landing buffer at the end of the previous sub-tile and those reads have long returned
         // (a flush lies in between); the buffer is free for the next sub-tile's pixels
         PHASE(7);
-        if (more) fetch(j + W, nxt_pb, nxt_pa, nxt_raw3);
+        if (more) fetch(mid_tag, j + W, nxt_pb, nxt_pa, nxt_raw3);
         PHASE(0);
 
         const uint32_t base = j * ENC_SUB;
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's before the stores of the flush join the memory queue
         if (more) {
-            take(cur, nxt_raw3);
+            take(cur, KIND == 2 ? false : nxt_raw3);
             cur_pb = nxt_pb.value();
             cur_pa = nxt_pa.value();
         }
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const uint32_t nfull = N / ENC_SUB;  // sub-tiles that lie fully inside the image
     if (!mono) {
         uint32_t j = w;
-        if (j < nfull) { NbrPx b_, a_; fetch(j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
+        if (j < nfull) { NbrPx b_, a_; fetch(std::integral_constant<int, 0>{}, j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
 #if !defined(SQOA_ENC_PRIO) || SQOA_ENC_PRIO
         // Progress-based wave priority.  The SIMD arbiter is oldest-first: of the images sharing a CU the oldest runs at
         // almost solo speed and the youngest finishes alone on a nearly idle CU (tools/trace_encode.py shows the staircase).
@@ -733,32 +738,36 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         __builtin_amdgcn_s_setprio(3);
         // MID instance of the body: not the wave's first sub-tile (j > 0), a full sub-tile behind it, and another one of this
         // wave's to prefetch (j + W < nfull - 1 ... all three known at compile time); the few others take the general instance
-        if (j < nfull) { body(std::true_type{}, std::false_type{}, j, j + W < nfull); j += W; }
-        const uint32_t nmid = nfull > (uint32_t)W ? nfull - (uint32_t)W : 0u;
-        for (; j < nmid; j += W) {
-            if (j >= thr) {
-                ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
-                if (q == 1) __builtin_amdgcn_s_setprio(2);
-                else if (q == 2) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
+        if (j < nfull) { body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull); j += W; }
+        const uint32_t nmid = nfull > (uint32_t)W + 1u ? nfull - (uint32_t)W - 1u : 0u;  // j + W is interior as well
+        auto hot_loop = [&](auto kind_tag) {
+            for (; j < nmid; j += W) {
+                if (j >= thr) {
+                    ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
+                    if (q == 1) __builtin_amdgcn_s_setprio(2);
+                    else if (q == 2) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                body(std::true_type{}, kind_tag, j, true);
             }
-            body(std::true_type{}, std::true_type{}, j, true);
-        }
-        for (; j < nfull; j += W) body(std::true_type{}, std::false_type{}, j, j + W < nfull);  // the image's last full sub-tile
+        };
+        if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
+        else hot_loop(std::integral_constant<int, 1>{});
+        for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
-        for (; j < nfull; j += W) body(std::true_type{}, std::false_type{}, j, j + W < nfull);
+        for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);
 #endif
         if (nsub > nfull && nfull % W == (uint32_t)w) {  // the image's partial last sub-tile
             NbrPx b_, a_;
-            fetch(nfull, b_, a_, cur_raw3);
+            fetch(std::integral_constant<int, 0>{}, nfull, b_, a_, cur_raw3);
             take(cur, cur_raw3);
             cur_pb = b_.value(); cur_pa = a_.value();
-            body(std::false_type{}, std::false_type{}, nfull, false);
+            body(std::false_type{}, std::integral_constant<int, 0>{}, nfull, false);
         }
     } else {
         uint32_t j = w;
-        if (j < nsub) { NbrPx b_, a_; fetch(j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
-        for (; j < nsub; j += W) body(std::false_type{}, std::false_type{}, j, j + W < nsub);
+        if (j < nsub) { NbrPx b_, a_; fetch(std::integral_constant<int, 0>{}, j, b_, a_, cur_raw3); take(cur, cur_raw3); cur_pb = b_.value(); cur_pa = a_.value(); }
+        for (; j < nsub; j += W) body(std::false_type{}, std::integral_constant<int, 0>{}, j, j + W < nsub);
     }
     if (st.bad && lane == 0) atomicMax(&results[jid].status, SQOA_HIP_ST_INTERNAL);
 #ifdef SQOA_TRACE
