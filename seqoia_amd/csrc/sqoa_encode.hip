@@ -519,6 +519,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             uint32_t dif = 0;
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+            asm volatile("" : "+v"(dif));  // one compare of the OR, not eight compares OR-ed on the scalar pipe
             flat = __ballot(dif != 0u) == 0ull;
         }
         if (flat) {
