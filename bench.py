@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: BASELINE.json configs[1]+[2] -- a batch of 1024 synthetic 1024x1024 RGBA
-images (SURVEY.md Appendix C class "mixed", seed 1) encoded to .sqoa streams and decoded back,
-device-resident, on N MI355X (one process per GPU, images sharded, no collective in the data path).
+"""Headline benchmark: BASELINE.json configs[1]+[2] -- a batch of 1024 synthetic 1024x1024 RGBA images (SURVEY.md
+Appendix C class "mixed", seed 1) encoded to .sqoa streams and decoded back, device-resident, on N MI355X: one process
+per GPU, the image list sharded over the ranks, no collective in the data path (images are independent work items; the
+per-image loop this replaces is sqoabench.c:575-628).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--images 1024] [--size 1024]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config headline|c5]
 
-One step = encode the rank's whole batch, then decode the streams just produced.  `value` is
-whole-job Mpixels/s over the K timed steps (pixels that went through encode AND decode, counted
-once).  The JSON line also carries the roofline of the dominant kernel (encode, HIP events on the
-kernel's own stream) and the reference seqoia.h timed on the host cores (rank 0, N=1 only).
+* ``--gpus N`` (N > 1) without a launcher: this process touches no GPU API; it starts N rank processes (RANK /
+  LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), relays rank 0's JSON line and
+  exits non-zero if any rank failed.  Under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` the
+  environment is already there and the process is a rank.
+* ``--scaling weak`` (default): 1024 images per GPU.  ``strong``: 1024 images in total, contiguous blocks per rank.
+* ``--config c5``: BASELINE.json configs[4], the qoi-suite-shaped set of 65 536 mixed-size images
+  (seqoia_amd/suite.py), longest-processing-time-first over the ranks on w*h; strong scaling by construction.
+
+One step = encode the rank's whole shard, then decode the streams just produced.  `value` is whole-job Mpixels/s over
+the K timed steps (pixels that went through encode AND decode, counted once; MAX over ranks of the time).  The JSON line
+also carries the roofline of both kernels (HIP events on the stream they run on), the secondary configurations
+(QOI-compat on the same batch, RGB icon sets) and the reference seqoia.h timed on the host cores (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,74 +31,322 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+METRIC = "Mpixels/s encode+decode, 1024-image RGBA batch; % HBM roofline"
 
 
-def cpu_baseline(width, height, channels, budget_s=12.0):
-    """Reference codec (oracle/_ref when present, else the restatement) on the host cores, on a
-    bounded sample of the same workload: as many images as fit ~budget_s, every core busy."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps; the first ~50 ms after an idle period run at lower clocks (tools/time_warm.py)")
+    ap.add_argument("--images", type=int, default=None, help="headline: images per GPU (weak) / in total (strong), default 1024; c5: images in total, default 65536")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--config", choices=("headline", "c5"), default="headline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the host-core reference leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (QOI-compat, icon sets)")
+    ap.add_argument("--graph", action="store_true", help="capture the step once into a HIP graph and replay it (same time: launch overhead is not what bounds the step)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report their shard (no GPU): launcher / sharding rehearsal")
+    return ap.parse_args(argv)
+
+
+# ---- launcher: --gpus N without torchrun -----------------------------------------------------------------------------
+
+
+def launch_ranks(n, argv):
+    """Start n rank processes of this script and relay rank 0's stdout.  Nothing here may touch a GPU API: a process
+    that has initialised HIP must not fork/exec the ranks (and this parent never imports torch)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.exit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
+# ---- the reference on the host cores -----------------------------------------------------------------------------------
+
+
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs among the allowed logical CPUs."""
+    allowed = os.sched_getaffinity(0)
+    seen = set()
+    for cpu in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", cpu))
+    return max(len(seen), 1), len(allowed)
+
+
+def cpu_baseline(width, height, channels):
+    """Reference codec (oracle/_ref when present, else the restatement) on the host cores, on a bounded sample of the same
+    workload: (i) one thread, sqoabench protocol -- one discarded warm-up run, mean of N runs,
+    malloc + free inside the timed region (sqoabench.c:394-406, :490-494, :527-538); (ii) T threads, T = physical cores,
+    every thread encoding + decoding images of its own."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle as po
 
     codec = po.best()
-    cores = len(os.sched_getaffinity(0))
-    per_thread = 8  # 8 x (encode + decode) of a 1 Mpixel image ~ 0.15 s per thread-iteration: ~20-40 s of CPU work in total
-    imgs = [po.synth(width, height, channels, "mixed", 1, i) for i in range(min(cores, 16))]
+    cores, logical = physical_cores()
+    px_img = width * height
+
+    # (i) one thread, the protocol of BENCHMARK_FN
+    runs = 5
+    px0 = po.synth(width, height, channels, "mixed", 1, 0)
+    enc0 = codec.encode(px0, width, height, channels, 0)
+    d, n, dd = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
+    t_enc = t_dec = 0.0
+    for i in range(-1, runs):  # run -1 is the warm-up
+        a = time.perf_counter()
+        codec.decode_raw(enc0, len(enc0), C.byref(dd), 4)
+        b = time.perf_counter()
+        codec.encode_raw(px0.ctypes.data, C.byref(d), C.byref(n))
+        c = time.perf_counter()
+        if i >= 0:
+            t_dec += b - a
+            t_enc += c - b
+    single = {"encode_mpps": round(px_img * runs / t_enc / 1e6, 1), "decode_mpps": round(px_img * runs / t_dec / 1e6, 1),
+              "runs": runs, "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of runs, malloc+free timed"}
+
+    # (ii) all physical cores, distinct images per thread
+    per_thread = 8  # images per thread: encode + decode of a 1 Mpixel image ~20 ms, so ~0.2 s of timed work per thread after its own synthesis
+
+    import threading
+
+    gate = threading.Barrier(cores)
 
     def work(t):
-        d = po.Desc(width, height, channels, 0, 0)
-        n = C.c_int(0)
-        dd = po.Desc()
-        px = imgs[t % len(imgs)]
-        enc = codec.encode(px, width, height, channels, 0)
-        t_enc = t_dec = 0.0
-        for _ in range(per_thread):
+        dl, nl, ddl = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
+        imgs = [po.synth(width, height, channels, "mixed", 1, t * per_thread + k) for k in range(per_thread)]
+        encs = [codec.encode(p, width, height, channels, 0) for p in imgs]
+        te = td = 0.0
+        gate.wait()  # every core enters the timed loop together
+        t0 = time.perf_counter()
+        for p, e in zip(imgs, encs):
             a = time.perf_counter()
-            codec.encode_raw(px.ctypes.data, C.byref(d), C.byref(n))  # malloc+free inside, sqoabench.c:527-538
+            codec.encode_raw(p.ctypes.data, C.byref(dl), C.byref(nl))  # malloc+free inside, sqoabench.c:527-538
             b = time.perf_counter()
-            codec.decode_raw(enc, len(enc), C.byref(dd), 4)           # sqoabench.c:490-494
+            codec.decode_raw(e, len(e), C.byref(ddl), 4)                # sqoabench.c:490-494
             c = time.perf_counter()
-            t_enc += b - a
-            t_dec += c - b
-        return t_enc, t_dec
+            te += b - a
+            td += c - b
+        return te, td, t0, time.perf_counter()
 
-    work(0)  # warm-up run, discarded (sqoabench.c:394-406)
-    t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         parts = list(ex.map(work, range(cores)))
-    wall = time.perf_counter() - t0
-    px_total = cores * per_thread * width * height
+    busy = max(p[3] for p in parts) - min(p[2] for p in parts)  # from the common start to the last thread's last call
+    px_total = cores * per_thread * px_img
     return {
-        "value": round(px_total / wall / 1e6, 1),
+        "value": round(px_total / busy / 1e6, 1),
         "unit": "Mpixels/s",
         "cores": cores,
+        "logical_cpus": logical,
         "kind": codec.kind,
-        "sample": f"{cores * per_thread} images {width}x{height}x{channels} (class mixed), encode+decode each, {cores} threads",
-        "encode_mpps_per_core": round(per_thread * width * height / (sum(p[0] for p in parts) / cores) / 1e6, 1),
-        "decode_mpps_per_core": round(per_thread * width * height / (sum(p[1] for p in parts) / cores) / 1e6, 1),
+        "sample": f"{cores * per_thread} distinct images {width}x{height}x{channels} (class mixed, seed 1), encode+decode each, {cores} threads (one per physical core)",
+        "encode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[0] for p in parts) / cores) / 1e6, 1),
+        "decode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[1] for p in parts) / cores) / 1e6, 1),
+        "single_thread": single,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=20, help="untimed steps; the first ~50 ms after an idle period run at lower clocks (tools/time_warm.py)")
-    ap.add_argument("--images", type=int, default=1024, help="images per GPU")
-    ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="capture the step once into a HIP graph and replay it (same time: launch overhead is not what bounds the step)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
-    args = ap.parse_args()
+# ---- workloads -------------------------------------------------------------------------------------------------------
+
+
+class Uniform:
+    """n same-shaped images in one tensor: EncodePlan -> DecodePlan."""
+
+    def __init__(self, sq, torch, dev, n, w, h, ch, cls, img0, qoi=0, check=True):
+        self.n, self.pixels = n, n * w * h
+        self.read_bytes = self.pixels * ch
+        self.px = torch.empty((n, h, w, ch), dtype=torch.uint8, device=dev)
+        sq.synth(self.px, cls, seed=1, img0=img0)
+        self.enc = sq.EncodePlan(self.px, qoi_compat=qoi)
+        self.enc.launch()
+        res = self.enc.results()
+        assert (res["status"] == 0).all(), "encode failed"
+        self.lens = res["len"].astype("int64")
+        self.enc_bytes = int(self.lens.sum())
+        self.dec = sq.DecodePlan(self.enc.out, res["len"], w, h, ch)
+        self.dec.launch()
+        dres = self.dec.results()
+        assert (dres["status"] == 0).all(), "decode failed"
+        if check:
+            assert torch.equal(self.dec.out, self.px), "round trip mismatch"  # sqoabench.c:448-455 on the whole batch
+        self.write_bytes = self.pixels * ch
+
+    def step(self, stream):
+        self.enc.launch(stream)
+        self.dec.launch(stream)
+
+    def close(self):
+        self.dec.close()
+        self.enc.close()
+
+
+class Suite:
+    """A rank's shard of the suite-shaped image list: EncodeList -> DecodeList (BASELINE.json configs[4])."""
+
+    def __init__(self, sq, torch, dev, shard):
+        self.n = len(shard)
+        self.idx = [im.index for im in shard]
+        sizes = [im.pixels * im.channels for im in shard]
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + ((s + 255) & ~255))
+        self.px = torch.empty((max(offs[-1], 1),), dtype=torch.uint8, device=dev)
+        images = []
+        for im, o, s in zip(shard, offs, sizes):
+            t = self.px[o : o + s]
+            sq.synth(t.view(1, im.height, im.width, im.channels), im.cls, seed=1, img0=im.index)
+            images.append((t, sq.Desc(im.width, im.height, im.channels, 0, 0)))
+        self.pixels = sum(im.pixels for im in shard)
+        self.read_bytes = sum(sizes)
+        self.write_bytes = self.read_bytes
+        self.enc = sq.EncodeList(images)
+        self.enc.launch()
+        res = self.enc.results()
+        assert (res["status"] == 0).all(), "encode failed"
+        self.lens = res["len"].astype("int64")
+        self.enc_bytes = int(self.lens.sum())
+        base = self.enc.out.data_ptr()
+        self.dec = sq.DecodeList([(base + o, int(l), im.width, im.height, im.channels)
+                                  for im, o, l in zip(shard, self.enc.offsets, res["len"])], device=dev.index or 0)
+        self.dec.launch()
+        dres = self.dec.results()
+        assert (dres["status"] == 0).all(), "decode failed"
+        for i, (o, s) in enumerate(zip(offs, sizes)):  # round trip of every image (sqoabench.c:448-455)
+            assert torch.equal(self.dec.image(i), self.px[o : o + s]), f"round trip mismatch, image {self.idx[i]}"
+
+    def step(self, stream):
+        self.enc.launch(stream)
+        self.dec.launch(stream)
+
+    def close(self):
+        self.dec.close()
+        self.enc.close()
+
+
+def kernel_times(wl, k):
+    """(encode ms, decode ms) per launch, HIP events on the plans' own stream."""
+    return wl.enc.time(k) / k, wl.dec.time(k) / k
+
+
+def secondary(sq, torch, dev, headline, k=5):
+    """Configurations BASELINE.json names besides the headline, timed outside ms_per_step with HIP events over k launches
+    after a warm-up launch each: QOI-compat (qoi_compat=1, the 64-entry running colour hash: seqoia.h:563-582, :753-760,
+    :785-787) on the headline batch, and configs[3], RUN-heavy 3-channel icon sets, in both wire formats.  Read-roofline
+    fraction = channels B/px / encode time / 8 TB/s; decode fraction = (stream + pixel bytes) / time / 8 TB/s."""
+    out = {}
+
+    def row(name, wl):
+        wl.enc.time(2), wl.dec.time(2)
+        e, d = kernel_times(wl, k)
+        out[name] = {
+            "encode_ms": round(e, 4), "decode_ms": round(d, 4),
+            "encode_mpps": round(wl.pixels / e / 1e3, 1), "decode_mpps": round(wl.pixels / d / 1e3, 1),
+            "rate": round(wl.enc_bytes / wl.read_bytes, 4),
+            "encode_read_roofline_frac": round(wl.read_bytes / e / 1e6 / HBM_PEAK_GBS, 4),
+            "decode_roofline_frac": round((wl.enc_bytes + wl.write_bytes) / d / 1e6 / HBM_PEAK_GBS, 4),
+        }
+        wl.close()
+
+    h = headline
+    n, hh, ww, ch = h.px.shape
+    wl = Uniform.__new__(Uniform)  # QOI-compat on the very same pixels
+    wl.n, wl.pixels, wl.read_bytes, wl.write_bytes, wl.px = h.n, h.pixels, h.read_bytes, h.write_bytes, h.px
+    wl.enc = sq.EncodePlan(h.px, qoi_compat=1)
+    wl.enc.launch()
+    res = wl.enc.results()
+    assert (res["status"] == 0).all()
+    wl.enc_bytes = int(res["len"].astype("int64").sum())
+    wl.dec = sq.DecodePlan(wl.enc.out, res["len"], ww, hh, ch)
+    wl.dec.launch()
+    assert (wl.dec.results()["status"] == 0).all() and torch.equal(wl.dec.out, h.px), "QOI-compat round trip mismatch"
+    row(f"qoi_compat=1, {n} x {ww}x{hh} RGBA (the headline batch)", wl)
+    for size in (512, 64):
+        for qoi in (0, 1):
+            row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi))
+    return out
+
+
+def traffic_from_profile(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, only when it was taken from THIS kernel source
+    (the summary records the hash of seqoia_amd/csrc); otherwise None."""
+    import hashlib
+
+    pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+    if not os.path.exists(pmc):
+        return None, None
+    d = json.load(open(pmc))
+    hsh = hashlib.sha256()
+    src = os.path.join(ROOT, "seqoia_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        hsh.update(open(os.path.join(src, f), "rb").read())
+    if d.get("csrc_sha256") != hsh.hexdigest():
+        return None, None
+    k = d["kernels"].get(kernel)
+    if not k:
+        return None, None
+    # gfx950: FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md, HBM); KB
+    return int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024), "profiles/pmc_hbm_latest.json"
+
+
+# ---- one rank --------------------------------------------------------------------------------------------------------
+
+
+def run_rank(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world} ranks", file=sys.stderr)
+
+    from seqoia_amd import shard as sh
+    from seqoia_amd import suite
+
+    c5 = args.config == "c5"
+    scaling = "strong" if c5 else args.scaling
+    n_total = args.images if args.images is not None else (suite.C5_IMAGES if c5 else 1024)
+    if c5:
+        mine = suite.shard(n_total, world, rank)
+    elif scaling == "strong":
+        mine = sh.contiguous(n_total, world, rank)
+    else:
+        mine = range(rank * n_total, (rank + 1) * n_total)
+
+    if args.dry_run:  # rendezvous + shard report only: rehearses the launcher and the partition without a GPU
+        import torch.distributed as dist
+
+        if world > 1:
+            dist.init_process_group("gloo")
+        cnt = len(mine)
+        allv = sh.gather_lengths([im.index for im in mine] if c5 else list(mine), [1] * cnt, n_total if (c5 or scaling == "strong") else n_total * world)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": scaling, "config": args.config, "images_rank0": cnt, "images_total": int(sum(allv))}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import torch
 
     import seqoia_amd as sq
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
     local = local % max(torch.cuda.device_count(), 1)  # rehearsal on a 1-GPU box: ranks share the device
@@ -101,51 +360,29 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    n, s, ch = args.images, args.size, 4
     dev = torch.device("cuda", local)
-    px = torch.empty((n, s, s, ch), dtype=torch.uint8, device=dev)
-    sq.synth(px, "mixed", seed=1, img0=rank * n)  # every rank owns a disjoint slice of the image list
-    enc = sq.EncodePlan(px, qoi_compat=0)
-    enc.launch()
-    res = enc.results()
-    assert (res["status"] == 0).all(), "encode failed"
-    enc_bytes = int(res["len"].sum())
-    dec = None
-    try:
-        dec = sq.DecodePlan(enc.out, res["len"], s, s, 4)
-        dec.launch()
-        dres = dec.results()
-        assert (dres["status"] == 0).all(), "decode failed"
-        assert torch.equal(dec.out, px), "round trip mismatch"  # sqoabench.c:448-455 on the whole batch
-    except sq.SqoaError as e:
-        if rank == 0:
-            print(f"[bench] decode leg unavailable: {e}", file=sys.stderr)
-        dec = None
+    s, ch = args.size, 4
+    if c5:
+        wl = Suite(sq, torch, dev, mine)
+    else:
+        wl = Uniform(sq, torch, dev, len(mine), s, s, ch, "mixed", mine[0] if len(mine) else 0)
 
     work_stream = torch.cuda.Stream(device=dev)  # both legs in order on one stream
     stream = work_stream.cuda_stream
-
-    def step():
-        enc.launch(stream)
-        if dec is not None:
-            dec.launch(stream)
-
-    # plan launches allocate nothing and never touch the host, so the step is captured once into a HIP graph and replayed
+    run = lambda: wl.step(stream)  # noqa: E731
     graph = None
-    if args.graph:
+    if args.graph:  # plan launches allocate nothing and never touch the host: the step can be captured once and replayed
         try:
-            step()
+            run()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=work_stream):
-                step()
+                wl.step(stream)
             run = graph.replay
         except Exception as e:  # noqa: BLE001 -- the direct path is always available
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({e}); launching directly", file=sys.stderr)
             graph = None
-    if graph is None:
-        run = step
 
     for _ in range(args.warmup):
         run()
@@ -161,21 +398,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    totals = [float(wl.pixels), float(wl.enc_bytes), float(wl.read_bytes)]
     if dist is not None:
-        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        on = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=on, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tt = torch.tensor(totals, device=on, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        totals = tt.tolist()
+    total_px, total_enc, total_read = totals
+
+    # per-image stream lengths in global order: the only cross-rank step, a few bytes per image, outside the timed region
+    n_global = n_total if (c5 or scaling == "strong") else n_total * world
+    all_lens = sh.gather_lengths(wl.idx if c5 else list(mine), wl.lens.tolist(), n_global)
 
     # per-kernel durations with HIP events on the stream the kernels run on (the plan's own)
     k = max(args.steps, 5)
-    enc_ms = enc.time(k) / k
-    dec_ms = dec.time(k) / k if dec is not None else None
+    enc_ms, dec_ms = kernel_times(wl, k)
 
-    pixels = n * s * s
-    total_px = pixels * world
-    read_bytes = pixels * ch
+    if c5:
+        workload = (f"C5: {n_total} qoi-suite-shaped images (seqoia_amd/suite.py: 64x64 .. 3840x2160, 3 and 4 channels), LPT-sharded on w*h over "
+                    f"{world} GPU(s): sqoa_encode qoi_compat=0 then sqoa_decode, device-resident")
+    else:
+        workload = (f"{n_total} x {s}x{s} RGBA (class mixed, seed 1) {'per GPU' if scaling == 'weak' else 'in total, contiguous blocks per rank'}: "
+                    f"sqoa_encode qoi_compat=0 then sqoa_decode to 4 channels, device-resident")
     out = {
-        "metric": "Mpixels/s encode+decode, 1024-image RGBA batch; % HBM roofline",
+        "metric": METRIC,
         "value": round(total_px * args.steps / dt / 1e6, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -183,53 +432,65 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"{n} x {s}x{s} RGBA (class mixed, seed 1) per GPU: sqoa_encode qoi_compat=0 then sqoa_decode to 4 channels, device-resident",
-            "images_per_gpu": n,
-            "encoded_bytes_per_gpu": enc_bytes,
-            "rate": round(enc_bytes / (pixels * ch), 4),
-            "decode_leg": dec is not None,
+            "workload": workload,
+            "images_rank0": wl.n,
+            "images_total": n_global,
+            "pixels_total": int(total_px),
+            "encoded_bytes_total": int(total_enc),
+            "encoded_bytes_check": int(sum(all_lens)),  # from the gathered per-image lengths: equals encoded_bytes_total
+            "rate": round(total_enc / total_read, 4),
             "launch": "hip graph replay" if graph is not None else "direct",
-            "encode_mpps_per_gpu": round(pixels / enc_ms / 1e3, 1),
-            "decode_mpps_per_gpu": round(pixels / dec_ms / 1e3, 1) if dec_ms else None,
-        },
-        "roofline": {
-            "kernel": "sqoa::encode_kernel",
-            "bound": "hbm",
-            "achieved": round(read_bytes / enc_ms / 1e6, 1),   # algorithmic READ bytes (4 B/px) / kernel time
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(read_bytes / enc_ms / 1e6 / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "achieved_read_plus_write": round((read_bytes + enc_bytes) / enc_ms / 1e6, 1),
-            "kernel_ms": round(enc_ms, 4),
+            "encode_mpps_rank0": round(wl.pixels / enc_ms / 1e3, 1),
+            "decode_mpps_rank0": round(wl.pixels / dec_ms / 1e3, 1),
+            "roofline_frac_of_n_gpus": round(total_px * args.steps / dt / (world * HBM_PEAK_GBS * 1e9 / 4), 4),
         },
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
-    if os.path.exists(pmc) and n == 1024 and s == 1024:
-        # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this
-        # same workload, corrected per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of streamed reads)
-        k_ = json.load(open(pmc))["kernels"].get("encode")
-        if k_:
-            out["roofline"]["traffic"] = int((2 * k_["FETCH_SIZE_KB"] + k_["WRITE_SIZE_KB"]) * 1024)
-            out["roofline"]["traffic_source"] = "profiles/pmc_hbm_latest.json"
-    if dec_ms:
-        out["roofline"]["decode"] = {
-            "kernel": "sqoa::decode_kernel",
-            "achieved": round((enc_bytes + pixels * 4) / dec_ms / 1e6, 1),
-            "frac": round((enc_bytes + pixels * 4) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
-            "kernel_ms": round(dec_ms, 4),
-        }
+    # Both kernels are HBM-bound by their algorithmic bytes; the decoder is the dominant one by time, the
+    # encoder is the one the north-star's target (>= 50 % of the HBM-read roofline) is stated on.
+    enc_traffic, src = traffic_from_profile("encode")
+    dec_traffic, _ = traffic_from_profile("decode")
+    dominant = "decode" if dec_ms >= enc_ms else "encode"
+    roof_enc = {
+        "kernel": "sqoa::encode_kernel<8,false>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "achieved": round(wl.read_bytes / enc_ms / 1e6, 1),  # algorithmic READ bytes (channels B/px) / kernel time
+        "frac": round(wl.read_bytes / enc_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "achieved_read_plus_write": round((wl.read_bytes + wl.enc_bytes) / enc_ms / 1e6, 1),
+        "kernel_ms": round(enc_ms, 4), "traffic": enc_traffic,
+    }
+    roof_dec = {
+        "kernel": "sqoa::decode_wave_kernel<8>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
+        "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "kernel_ms": round(dec_ms, 4), "traffic": dec_traffic,
+    }
+    out["roofline"] = dict(roof_dec if dominant == "decode" else roof_enc)
+    out["roofline"]["dominant_by_time"] = dominant
+    out["roofline"]["share_of_step"] = round(max(enc_ms, dec_ms) / (enc_ms + dec_ms), 3)
+    if src:
+        out["roofline"]["traffic_source"] = src
+    out["roofline"]["encode"] = roof_enc
+    out["roofline"]["decode"] = roof_dec
+    if rank == 0 and world == 1 and not c5 and not args.no_secondary:
+        out["config"]["secondary"] = secondary(sq, torch, dev, wl)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(s, s, ch)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -31,8 +31,9 @@ extern "C" {
  * seqoia.h:527-542), dst = output slot of at least sqoa_hip_encode_bound()
  * bytes.  Decode: src = stream of src_size bytes (readable up to the next
  * multiple of 16), dst = width*height*out_channels bytes, desc.channels = the
- * `channels` argument of sqoa_decode (0..4), width/height = what the caller
- * expects (checked against the header). */
+ * `channels` argument of sqoa_decode (0..4), width/height = the shape the caller
+ * laid dst out for: a stream whose header says otherwise is SQOA_HIP_ST_BADARG
+ * (0 = take whatever the header says; dst_cap still bounds the write). */
 typedef struct {
     unsigned long long src;      /* device address */
     unsigned long long dst;      /* device address */

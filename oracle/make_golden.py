@@ -137,11 +137,30 @@ def decode_cases(ref):
     return c
 
 
+def headline_digests(ref, n=1024, w=1024, h=1024, ch=4, seed=1):
+    """Length + FNV-1a-64 of EVERY stream of the headline batch (BASELINE.json configs[1]: class mixed, seed 1,
+    img 0..n-1) in both wire formats, from the compiled reference (seqoia.h:456-650).  ctypes calls release the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(img):
+        px = po.synth(w, h, ch, "mixed", seed, img)
+        s, q = ref.encode(px, w, h, ch, 0), ref.encode(px, w, h, ch, 1)
+        return [len(s), f"{po.fnv1a64(s):016x}", len(q), f"{po.fnv1a64(q):016x}"]
+
+    with ThreadPoolExecutor(len(os.sched_getaffinity(0))) as ex:
+        rows = list(ex.map(one, range(n)))
+    return dict(cls="mixed", w=w, h=h, channels=ch, seed=seed, count=n, columns=["sqoa_len", "sqoa_fnv", "qoi_len", "qoi_fnv"], rows=rows)
+
+
 def main():
     ref = po.reference()
     if ref is None:
         sys.exit("oracle/_ref/libsqoa_ref.so missing and /root/reference absent: cannot regenerate goldens")
     os.makedirs(OUT, exist_ok=True)
+    if "--headline" in sys.argv:  # only the (slow) whole-batch digest table
+        json.dump(headline_digests(ref), open(os.path.join(OUT, "headline_digests.json"), "w"), separators=(",", ":"))
+        print("wrote headline_digests.json")
+        return
 
     enc = []
     for c in encode_cases():

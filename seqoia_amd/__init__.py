@@ -8,6 +8,7 @@ from ._lib import Desc, Job, Result, SqoaError, LIB_PATH, load  # noqa: F401
 from .api import (  # noqa: F401
     SQOA_LINEAR,
     SQOA_SRGB,
+    DecodeList,
     DecodePlan,
     EncodeList,
     EncodePlan,
@@ -15,6 +16,7 @@ from .api import (  # noqa: F401
     decode,
     encode,
     encode_bound,
+    fnv1a64,
     read,
     stride_channels,
     synth,

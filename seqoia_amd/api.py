@@ -232,6 +232,44 @@ class DecodePlan(Plan):
         super().__init__(DECODE, jobs, _device_index(streams))
 
 
+class DecodeList(Plan):
+    """Decode streams of different shapes in one plan (BASELINE config 5 shape).
+
+    ``items``: list of (device address of the stream, stream bytes, width, height, out_channels).  Every image decodes
+    to width*height*out_channels bytes at ``self.offsets[i]`` of ``self.out`` (offsets are multiples of 4, so that
+    4-channel images are stored as dwords)."""
+
+    def __init__(self, items, device: int = 0, channels_arg=None):
+        import torch
+
+        self.items = list(items)
+        self.offsets = [0]
+        for _, _, w, h, oc in self.items:
+            self.offsets.append(self.offsets[-1] + ((w * h * oc + 3) & ~3))
+        self.out = torch.empty((max(self.offsets[-1], 1),), dtype=torch.uint8, device=torch.device("cuda", device))
+        base = self.out.data_ptr()
+        jobs = []
+        for (src, size, w, h, oc), off in zip(self.items, self.offsets):
+            arg = oc if channels_arg is None else channels_arg
+            jobs.append(Job(src, base + off, int(size), min(w * h * oc, 0xFFFFFFFF), Desc(w, h, arg, 0, 0), 0))
+        super().__init__(DECODE, jobs, device)
+
+    def image(self, i):
+        """Decoded pixels of image i as a flat uint8 CUDA tensor (a view of self.out)."""
+        _, _, w, h, oc = self.items[i]
+        return self.out[self.offsets[i] : self.offsets[i] + w * h * oc]
+
+
+def fnv1a64(ptrs, lens, device: int = 0):
+    """FNV-1a-64 of device buffers (one digest per buffer), computed on the device: size-independent parity checks."""
+    n = len(ptrs)
+    p = (C.c_ulonglong * max(n, 1))(*[int(x) for x in ptrs])
+    l = (C.c_uint * max(n, 1))(*[int(x) for x in lens])
+    out = (C.c_ulonglong * max(n, 1))()
+    check(_lib.load().sqoa_hip_fnv1a64(device, p, l, n, out), "sqoa_hip_fnv1a64")
+    return [int(out[i]) for i in range(n)]
+
+
 def synth(out, cls: str = "mixed", seed: int = 1, img0: int = 0):
     """Fill a torch uint8 CUDA tensor [n, h, w, c] (c in 3,4) with the synthetic images of SURVEY.md Appendix C."""
     n, h, w, c = out.shape

@@ -488,7 +488,8 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
     if (only_slowpath && threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;
 
     const Hdr h = parse_header((gcptr8)job.src, res, threadIdx.x == 0);
-    if (!h.ok) { if (threadIdx.x == 0) res->status = SQOA_HIP_ST_BADARG; return; }
+    const bool shape_ok = (job.desc.width == 0 || job.desc.width == h.width) && (job.desc.height == 0 || job.desc.height == h.height);
+    if (!h.ok || !shape_ok) { if (threadIdx.x == 0) res->status = SQOA_HIP_ST_BADARG; return; }
     const uint32_t oc = job.desc.channels ? job.desc.channels : (h.channels < 3 ? 1u : 3u) + ((h.channels & 1u) ? 0u : 1u);
     // what the record pipeline takes: QOI-compat colour streams and SQOA mono streams, any output channel count
     const bool mono = !h.qoi && h.channels < 3;

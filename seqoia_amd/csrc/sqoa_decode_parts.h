@@ -62,16 +62,20 @@ typedef const __attribute__((address_space(3))) u32x4* lcptr128;
 SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
 SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
 
-// fill out[p0, p0+cnt) (pixel units) with v; OC = 3 or 4 output channels
+// one colour pixel at pixel index P; OC = 3 or 4 output channels, 40 = four channels at an address that is not dword-aligned
+template <int OC>
+SQOA_DEV void put_pixel(gptr8 out, uint32_t P, uint32_t v) {
+    if (OC == 4) ((gptr32)out)[P] = v;
+    else {
+        gptr8 o = out + (size_t)P * (OC == 3 ? 3 : 4);
+        o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
+        if (OC == 40) o[3] = (uint8_t)(v >> 24);
+    }
+}
+// fill out[p0, p0+cnt) (pixel units) with v
 template <int OC>
 SQOA_DEV void fill_pixels(gptr8 out, uint32_t p0, uint32_t cnt, uint32_t v, int lane) {
-    for (uint32_t k = lane; k < cnt; k += 64) {
-        if (OC == 4) ((gptr32)out)[p0 + k] = v;
-        else {
-            gptr8 o = out + (size_t)(p0 + k) * 3;
-            o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
-        }
-    }
+    for (uint32_t k = lane; k < cnt; k += 64) put_pixel<OC>(out, p0 + k, v);
 }
 
 // A pixel transform: v8 holds 4 packed channels, `abs` the byte mask of channels that are absolute;

@@ -120,7 +120,10 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
                           (magic == 0x716f6966u && !q) || hh >= 400000000u / hw);
         uint32_t path = 1;
-        if (!ok) { res->status = SQOA_HIP_ST_BADARG; path = 2; }
+        // a caller that states the shape it expects (non-zero job.desc.width / height) gets BADARG for any other header:
+        // its output buffer is laid out for that shape
+        const bool shape_ok = (job.desc.width == 0 || job.desc.width == hw) && (job.desc.height == 0 || job.desc.height == hh);
+        if (!ok || !shape_ok) { res->status = SQOA_HIP_ST_BADARG; path = 2; }
         else {
             const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
             if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const int oc = (int)bcast_first(job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u));
     // Streams packed back to back (sqoa_hip_pack) start at any byte address: all stream offsets below are relative to the
     // dword-aligned address at or in front of the stream; the `soff` bytes in front of it are loaded but never looked at.
+    const bool dw_out = (job.dst & 3ull) == 0;  // 4-channel pixels can be stored as dwords
     const uint32_t soff = (uint32_t)(job.src & 3ull);
     gcptr8 srca = src - soff;
     const uint32_t size_a = size + soff;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         if (pos_in < N) {
             const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
-            const bool plain = oc == 4 && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
+            const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
             if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
@@ -360,14 +364,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     const uint32_t P = lane_p + (m & 0x1fffu);
                     const uint32_t am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
-                    if (cnt >= 1u && cnt <= 2u && P < N) {
-                        if (OC == 4) ((gptr32)out)[P] = v;
-                        else { gptr8 o = out + (size_t)P * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
-                    }
-                    if (cnt == 2u && P + 1u < N) {
-                        if (OC == 4) ((gptr32)out)[P + 1u] = v;
-                        else { gptr8 o = out + (size_t)(P + 1u) * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
-                    }
+                    if (cnt >= 1u && cnt <= 2u && P < N) put_pixel<OC>(out, P, v);
+                    if (cnt == 2u && P + 1u < N) put_pixel<OC>(out, P + 1u, v);
                     unsigned long long runs = __ballot(cnt > 2u && P < N);
                     while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
                         const int l = __builtin_ctzll(runs);
@@ -379,14 +377,16 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     }
                 }
             };
-            if (oc == 4) store_ops(std::integral_constant<int, 4>{});
+            if (oc == 4 && dw_out) store_ops(std::integral_constant<int, 4>{});
+            else if (oc == 4) store_ops(std::integral_constant<int, 40>{});
             else store_ops(std::integral_constant<int, 3>{});
             }
         }
         DPHASE(5);
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
-                if (oc == 4) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                if (oc == 4 && dw_out) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                else if (oc == 4) fill_pixels<40>(out, pos_out, N - pos_out, exit_v, lane);
                 else fill_pixels<3>(out, pos_out, N - pos_out, exit_v, lane);
             }
             if (lane == 0) res->len = (int)(N * (uint32_t)oc);

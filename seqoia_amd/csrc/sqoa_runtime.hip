@@ -43,7 +43,20 @@ struct sqoa_hip_plan {
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr;       // recorded behind the kernels of the most recent launch, on whatever stream it used
+    bool pending = false;               // ev_done has been recorded since the last wait
 };
+
+// Wait for the most recent launch of the plan, whichever stream it went to (a launch captured into a graph records
+// nothing: whoever replays the graph synchronises the replay).
+static hipError_t plan_wait(sqoa_hip_plan* p) {
+    if (p->pending) {
+        hipError_t e = hipEventSynchronize(p->ev_done);
+        if (e != hipSuccess) return e;
+        p->pending = false;
+    }
+    return hipStreamSynchronize(p->stream);
+}
 
 extern "C" {
 
@@ -149,7 +162,7 @@ int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, 
     if ((e = hipMalloc((void**)&p->d_jobs, jb)) != hipSuccess || (e = hipMalloc((void**)&p->d_results, rb)) != hipSuccess ||
         (e = hipMalloc((void**)&p->d_init, rb)) != hipSuccess || (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&p->ev0)) != hipSuccess ||
-        (e = hipEventCreate(&p->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&p->ev1)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming)) != hipSuccess) {
         sqoa_hip_plan_destroy(p);
         return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan_create: allocation", e);
     }
@@ -162,14 +175,15 @@ int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, 
 int sqoa_hip_plan_update(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     if (!p || !jobs || n < 0 || n > p->cap) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_update: bad arguments");
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
-    HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
+    HIP_TRY(plan_wait(p), SQOA_HIP_ELAUNCH);  // the job table may still be read by a launch on the caller's stream
     return plan_fill(p, jobs, n);
 }
 
 void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (!p) return;
     hipSetDevice(p->device);
-    if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->stream) plan_wait(p);
+    if (p->ev_done) hipEventDestroy(p->ev_done);
     if (p->d_jobs) hipFree(p->d_jobs);
     if (p->d_results) hipFree(p->d_results);
     if (p->d_init) hipFree(p->d_init);
@@ -180,10 +194,9 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     delete p;
 }
 
-int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
-    if (!p) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_launch: null plan");
-    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
     if (p->n == 0) return 0;
+    HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);  // the calling thread's current device may be another one
     HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
     if (p->kind == SQOA_HIP_ENCODE) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids, p->n_sqoa, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
@@ -194,10 +207,26 @@ int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
     return 0;
 }
 
+int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
+    if (!p) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_launch: null plan");
+    hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+    if (p->n == 0) return 0;
+    int rc = plan_enqueue(p, s);
+    if (rc) return rc;
+    // results / update / destroy wait for THIS launch, not just for the plan's own stream
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (cap == hipStreamCaptureStatusNone) {
+        HIP_TRY(hipEventRecord(p->ev_done, s), SQOA_HIP_ELAUNCH);
+        p->pending = true;
+    }
+    return 0;
+}
+
 int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
-    HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
+    HIP_TRY(plan_wait(p), SQOA_HIP_ELAUNCH);
     if (n) HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
     return 0;
 }
@@ -207,7 +236,7 @@ int sqoa_hip_plan_time(sqoa_hip_plan* p, int iters, float* ms_total) {
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
     HIP_TRY(hipEventRecord(p->ev0, p->stream), SQOA_HIP_ELAUNCH);
     for (int i = 0; i < iters; ++i) {
-        int rc = sqoa_hip_plan_launch(p, nullptr);
+        int rc = plan_enqueue(p, p->stream);
         if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(p->ev1, p->stream), SQOA_HIP_ELAUNCH);
@@ -326,8 +355,17 @@ __global__ void fnv_kernel(const unsigned long long* __restrict__ ptrs, const ui
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* p = reinterpret_cast<const uint8_t*>(ptrs[i]);
+    const uint32_t len = lens[i];
     unsigned long long h = 0xcbf29ce484222325ull;
-    for (uint32_t k = 0; k < lens[i]; ++k) h = (h ^ p[k]) * 0x100000001b3ull;
+    uint32_t k = 0;
+    for (; k < len && ((uintptr_t)(p + k) & 15u); ++k) h = (h ^ p[k]) * 0x100000001b3ull;
+    for (; k + 16u <= len; k += 16u) {  // one 16-byte load per 16 steps of the chain
+        const uint4 q = *reinterpret_cast<const uint4*>(p + k);
+        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h = (h ^ ((d[j >> 2] >> (8 * (j & 3))) & 0xffu)) * 0x100000001b3ull;
+    }
+    for (; k < len; ++k) h = (h ^ p[k]) * 0x100000001b3ull;
     out[i] = h;
 }
 
@@ -387,16 +425,19 @@ int sqoa_hip_fnv1a64(int device, const unsigned long long* dptrs, const unsigned
     if (!dptrs || !lens || !digests || n < 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_fnv1a64: bad arguments");
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
-    unsigned long long *d_p = nullptr, *d_o = nullptr;
-    uint32_t* d_l = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_p, 8 * (size_t)n), SQOA_HIP_ENOMEM);
-    HIP_TRY(hipMalloc((void**)&d_o, 8 * (size_t)n), SQOA_HIP_ENOMEM);
-    HIP_TRY(hipMalloc((void**)&d_l, 4 * (size_t)n), SQOA_HIP_ENOMEM);
-    hipMemcpy(d_p, dptrs, 8 * (size_t)n, hipMemcpyHostToDevice);
-    hipMemcpy(d_l, lens, 4 * (size_t)n, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(sqoa::fnv_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, d_p, d_l, n, d_o);
-    hipError_t e = hipMemcpy(digests, d_o, 8 * (size_t)n, hipMemcpyDeviceToHost);
-    hipFree(d_p); hipFree(d_o); hipFree(d_l);
+    // one allocation: [n pointers | n digests | n lengths]
+    unsigned long long* d_p = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_p, 20 * (size_t)n), SQOA_HIP_ENOMEM);
+    unsigned long long* d_o = d_p + n;
+    uint32_t* d_l = (uint32_t*)(d_o + n);
+    hipError_t e = hipMemcpy(d_p, dptrs, 8 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_l, lens, 4 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sqoa::fnv_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, d_p, d_l, n, d_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(digests, d_o, 8 * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(d_p);
     HIP_TRY(e, SQOA_HIP_ELAUNCH);
     return 0;
 }

@@ -205,29 +205,139 @@ def test_wave_decoder_chunk_boundaries(sq, orc):
 
 
 def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
-    """BASELINE configs 2+3 at full size: 1024 x 1024x1024 RGBA.  Size-independent properties: every status
-    OK, decode(encode(px)) == px for the whole batch (sqoabench.c:448-455), total length of images 0-15 equal to
-    the reference's, and byte-for-byte equality with the oracle on a sample."""
+    """BASELINE configs 2+3 at full size: 1024 x 1024x1024 RGBA, BOTH wire formats.  Every one of the 2 x 1024 streams
+    is pinned to the compiled reference (seqoia.h:456-650) by length and FNV-1a-64 (tests/golden/headline_digests.json,
+    written by oracle/make_golden.py --headline), the digests computed on the device; plus every status OK,
+    decode(encode(px)) == px for the whole batch (sqoabench.c:448-455), and byte-for-byte equality with the oracle on a sample."""
     import torch
 
-    n = 1024
+    from conftest import load_golden
+
+    gold = load_golden("headline_digests.json")
+    n = gold["count"]
+    assert (n, gold["w"], gold["h"], gold["channels"], gold["seed"]) == (1024, 1024, 1024, 4, 1)
     px = torch.empty((n, 1024, 1024, 4), dtype=torch.uint8, device="cuda")
     sq.synth(px, "mixed", seed=1, img0=0)
-    enc = sq.EncodePlan(px, qoi_compat=0)
-    enc.launch()
-    res = enc.results()
-    assert (res["status"] == 0).all()
-    assert int(res["len"][:16].sum()) == synth_digests["totals"]["mixed_1024_rgba_0_15"]["sqoa_total"]
-    dec = sq.DecodePlan(enc.out, res["len"], 1024, 1024, 4)
-    dec.launch()
-    dres = dec.results()
-    assert (dres["status"] == 0).all() and (dres["len"] == 4 << 20).all()
-    assert torch.equal(dec.out, px)
     o = orc.best()
-    for k in (5, 511, 1023):
-        assert enc.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, 0)
-    dec.close()
+    for mode in (0, 1):
+        enc = sq.EncodePlan(px, qoi_compat=mode)
+        enc.launch()
+        res = enc.results()
+        assert (res["status"] == 0).all()
+        want_len = [r[2 * mode] for r in gold["rows"]]
+        want_fnv = [int(r[2 * mode + 1], 16) for r in gold["rows"]]
+        assert res["len"].tolist() == want_len
+        base = enc.out.data_ptr()
+        got_fnv = sq.fnv1a64([base + i * enc.slot for i in range(n)], want_len)
+        bad = [i for i in range(n) if got_fnv[i] != want_fnv[i]]
+        assert not bad, (mode, bad[:8])
+        if mode == 0:
+            assert int(res["len"][:16].sum()) == synth_digests["totals"]["mixed_1024_rgba_0_15"]["sqoa_total"]
+        dec = sq.DecodePlan(enc.out, res["len"], 1024, 1024, 4)
+        dec.launch()
+        dres = dec.results()
+        assert (dres["status"] == 0).all() and (dres["len"] == 4 << 20).all()
+        assert torch.equal(dec.out, px)
+        for k in (5, 1023):
+            assert enc.streams([k])[0] == o.encode(orc.synth(1024, 1024, 4, "mixed", 1, k), 1024, 1024, 4, mode)
+        dec.close()
+        enc.close()
+        del dec, enc
+
+
+def test_c5_rank0_of_8_shard(sq, orc):
+    """BASELINE configs[4] as one of its 8 ranks sees it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
+    LPT-sharded on w*h, rank 0's 8 192 images in ONE encode plan and ONE decode plan (the workload class of
+    `bench.py --config c5 --gpus 8`): every status OK, every image round-trips exactly (sqoabench.c:448-455, one result per
+    image as in sqoabench.c:575-628), and a sample of streams from every directory is byte-equal to the oracle's."""
+    import torch
+
+    import bench
+    from seqoia_amd import suite
+
+    shard = suite.shard(suite.C5_IMAGES, 8, 0)
+    assert len(shard) > 8000
+    wl = bench.Suite(sq, torch, torch.device("cuda", 0), shard)  # asserts statuses and the round trip of every image
+    assert wl.pixels == sum(im.pixels for im in shard)
+    streams_at = wl.enc.offsets
+    o = orc.best()
+    seen = set()
+    for i, im in enumerate(shard):
+        if im.directory in seen or im.pixels > 2_000_000:
+            continue
+        seen.add(im.directory)
+        got = bytes(wl.enc.out[streams_at[i] : streams_at[i] + int(wl.lens[i])].cpu().numpy())
+        assert got == o.encode(orc.synth(im.width, im.height, im.channels, im.cls, 1, im.index), im.width, im.height, im.channels, 0), im
+    assert len(seen) >= 12
+    wl.step(0)  # the timed step of bench.py is repeatable: same lengths after a second encode + decode
+    torch.cuda.synchronize()
+    assert (wl.enc.results()["len"].astype("int64") == wl.lens).all()
+    wl.close()
+
+
+def test_results_wait_for_a_launch_on_the_callers_stream(sq, orc):
+    """sqoa_hip_plan_launch(plan, user_stream) followed by sqoa_hip_plan_results with NO other synchronisation: results
+    must wait for that launch (the plan records an event behind its kernels on whatever stream they went to)."""
+    import torch
+
+    n, w, h = 64, 1024, 1024
+    px = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=5, img0=0)
+    torch.cuda.synchronize()
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    side = torch.cuda.Stream()
+    want = None
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            filler = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").fill_(rep)  # keeps the side stream busy in front of the launch
+        enc.launch(side.cuda_stream)
+        res = enc.results()  # no torch.cuda.synchronize() here on purpose
+        assert (res["status"] == 0).all() and (res["len"] > 22).all(), rep
+        if want is None:
+            torch.cuda.synchronize()
+            want = enc.results()["len"].copy()
+        assert (res["len"] == want).all(), rep
+        del filler
+    o = orc.best()
+    assert enc.streams([3])[0] == o.encode(orc.synth(w, h, 4, "mixed", 5, 3), w, h, 4, 0)
     enc.close()
+
+
+def test_decode_to_unaligned_rgba_destination_and_shape_check(sq, orc):
+    """A 4-channel destination that is not dword-aligned takes byte stores (every decoder); a stream whose header does
+    not have the shape the job states is refused (SQOA_HIP_ST_BADARG) instead of being written with scrambled rows."""
+    import torch
+
+    from seqoia_amd import Desc, Job
+    from seqoia_amd._lib import DECODE
+
+    o = orc.best()
+    w, h = 300, 200
+    cases = []
+    for mode, ch, cls in ((0, 4, "mixed"), (0, 3, "photo"), (1, 4, "mixed"), (0, 4, "icon")):
+        px = orc.synth(w, h, ch, cls, 6, mode + ch)
+        cases.append((o.encode(px, w, h, ch, mode), o))
+    blob = b"".join(s + bytes(-len(s) % 16 + 16) for s, _ in cases)
+    src = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    out = torch.zeros((len(cases), w * h * 4 + 8), dtype=torch.uint8, device="cuda")
+    jobs, off = [], 0
+    for k, (s, _) in enumerate(cases):
+        jobs.append(Job(src.data_ptr() + off, out[k].data_ptr() + 1 + (k & 1) * 2, len(s), w * h * 4, Desc(w, h, 4, 0, 0), 0))
+        off += len(s) + (-len(s) % 16 + 16)
+    # same streams, but the caller expects another shape with the same pixel count
+    jobs.append(Job(src.data_ptr(), out[0].data_ptr(), len(cases[0][0]), w * h * 4, Desc(h, w, 4, 0, 0), 0))
+    plan = sq.Plan(DECODE, jobs)
+    plan.launch()
+    res = plan.results()
+    outc = out.cpu().numpy()
+    for k, (s, _) in enumerate(cases):
+        want, _ = o.decode(s, 4)
+        a = 1 + (k & 1) * 2
+        assert res["status"][k] == 0, k
+        assert outc[k, a : a + w * h * 4].tobytes() == want.tobytes(), k
+        assert outc[k, :a].tobytes() == bytes(a) and outc[k, a + w * h * 4 :].tobytes() == bytes(8 - a), k  # nothing outside
+    assert res["status"][len(cases)] == 1 and res["len"][len(cases)] == 0
+    plan.close()
 
 
 def test_plans_replay_from_a_hip_graph(sq, orc):

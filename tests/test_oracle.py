@@ -95,3 +95,24 @@ def test_restatement_equals_reference_on_random_streams():
                 if oa is not None:
                     assert oa.tobytes() == ob.tobytes()
                     assert bytes(da) == bytes(db)
+
+
+def test_headline_digest_table_is_consistent():
+    """tests/golden/headline_digests.json (all 1024 streams of the headline batch, both wire formats, from the compiled
+    reference) agrees with the independent fixtures in synth_digests.json and with the restatement on a sample."""
+    from conftest import load_golden
+
+    g = load_golden("headline_digests.json")
+    d = load_golden("synth_digests.json")
+    rows = g["rows"]
+    assert len(rows) == g["count"] == 1024
+    for c in d["images"]:
+        if (c["cls"], c["w"], c["h"], c["channels"], c["seed"]) == ("mixed", 1024, 1024, 4, 1):
+            assert rows[c["img"]] == [c["sqoa_len"], c["sqoa_fnv"], c["qoi_len"], c["qoi_fnv"]]
+    t = d["totals"]["mixed_1024_rgba_0_15"]
+    assert sum(r[0] for r in rows[:16]) == t["sqoa_total"] and sum(r[2] for r in rows[:16]) == t["qoi_total"]
+    orc = po.restatement()
+    for img in (7, 600):
+        px = po.synth(1024, 1024, 4, "mixed", 1, img)
+        s, q = orc.encode(px, 1024, 1024, 4, 0), orc.encode(px, 1024, 1024, 4, 1)
+        assert rows[img] == [len(s), f"{po.fnv1a64(s):016x}", len(q), f"{po.fnv1a64(q):016x}"]

@@ -77,3 +77,65 @@ def test_two_ranks_gloo_reproduce_single_rank():
     want = [len(po.restatement().encode(po.synth(w, h, ch, "mixed", 3, i), w, h, ch, 0)) for i, (w, h, ch) in enumerate(shapes)]
     assert allv == want
     assert tmax == 2.0
+
+
+def _bench(*argv):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_gpus_flag_starts_that_many_ranks(n):
+    """`python bench.py --gpus N` must itself start N ranks (RANK / WORLD_SIZE / MASTER_* in their environment) and
+    relay rank 0's line; --dry-run makes the ranks rendezvous over gloo and report their shards without a GPU."""
+    out = _bench("--gpus", str(n), "--dry-run")
+    assert out["n_gpus"] == n and out["scaling"] == "weak" and out["images_rank0"] == 1024 and out["images_total"] == 1024 * n
+    out = _bench("--gpus", str(n), "--dry-run", "--scaling", "strong")
+    assert out["n_gpus"] == n and out["scaling"] == "strong" and out["images_total"] == 1024
+    assert out["images_rank0"] == len(shard.contiguous(1024, n, 0))
+
+
+def test_bench_under_an_external_launcher_is_a_rank():
+    """Under torch.distributed.run the environment is already there: bench.py must not start ranks of its own."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--config", "c5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # one line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"] == "c5" and out["scaling"] == "strong" and out["images_total"] == 65536
+
+
+def test_c5_suite_table_and_lpt_shards():
+    """BASELINE.json configs[4]: the suite-shaped table replicated to 65 536 images and
+    LPT-sharded over 8 ranks on w*h: every image exactly once, pixel loads within 1 % of each other."""
+    from seqoia_amd import suite
+
+    rep = suite.replica()
+    assert len(rep) == 2871
+    px = sum(w * h for _, w, h, _, _ in rep)
+    assert abs(px - 1.32e9) / 1.32e9 < 0.01  # bench1-noaverage.txt:118-123: about 1.32 Gpx
+    imgs = suite.images()
+    assert len(imgs) == 65536 and [im.index for im in imgs] == list(range(65536))
+    assert {im.channels for im in imgs} == {3, 4} and max(im.pixels for im in imgs) == 3840 * 2160 and min(im.pixels for im in imgs) == 64 * 64
+    parts = [suite.shard(65536, 8, r) for r in range(8)]
+    assert sorted(im.index for p in parts for im in p) == list(range(65536))
+    loads = [sum(im.pixels for im in p) for p in parts]
+    assert max(loads) / min(loads) < 1.01
