@@ -31,7 +31,6 @@ namespace sqoa {
 constexpr int ENC_S = 8;               // steps per sub-tile
 constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
 constexpr int ENC_STG = 2624;          // staging bytes per wave: 5 B/px * 512, + 9 (run flush) + 12 (OR window) + 16 (clear), multiple of 16
-constexpr int ENC_SINK = 272;          // behind it: one dword sink per lane (+1), where pixels that emit nothing OR their zeros
 constexpr int ENC_PRE = ENC_SUB * 4;   // landing buffer of the next sub-tile's pixels (global -> LDS without passing VGPRs)
 constexpr uint32_t SPIN_MAX = 1u << 22;
 
@@ -108,6 +107,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
 SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
+#if defined(SQOA_ENC_FLUSH_ALIGNED)
     uint32_t a = (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u;
     if (a > T) a = T;
     if ((uint32_t)lane < a) g[lane] = stage[lane];
@@ -120,8 +120,28 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     const uint32_t t0 = a + 16u * nb;
     if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
     for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+#else
+    // 16-byte pieces: aligned LDS reads, global stores at whatever alignment the stream position has (unaligned vector
+    // stores cost nothing measurable here; the lines are completed in L2 by the neighbouring sub-tiles' flushes); the last
+    // T mod 16 bytes one by one.  T <= ENC_STG: at most three pieces per lane.
+    typedef u32x4 u32x4_una __attribute__((aligned(1)));
+    typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
+    const uint32_t nb = T >> 4;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < (ENC_STG + 1023) / 1024; ++k) {
+        const uint32_t u = (uint32_t)lane + 64u * k;
+        if (u < nb) {
+            ((gptr128u)g)[u] = *reinterpret_cast<const u32x4*>(stage + 16u * u);
+            *reinterpret_cast<uint4*>(stage + 16u * u) = zero;
+        }
+    }
+    const uint32_t t0 = nb << 4;
+    if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
+    // the partial piece and the 12 bytes of OR window behind it
+    if (lane < 2) *reinterpret_cast<uint4*>(stage + t0 + 16u * lane) = zero;
+#endif
 }
-
 
 // ---- SWAR main pass: four 64-pixel rows at a time, one byte lane per row -------------------------------
 // gfx950 issues add / sub / logic / right-shift / bitop3 on VGPR or literal operands at 1.7x the rate of every other
@@ -154,14 +174,57 @@ SQOA_DEV RunOut run_row(unsigned long long e, uint32_t crun, unsigned long long 
 
 struct SwarGroup { uint32_t W0, W1, W2, W3, AH, b0, Nn; };  // bytes 0..3 and 4 of every pixel's literal op (byte i = row i)
 
+// SQOA-native op decision (seqoia.h:606-634) for four pixels at once, bytewise: the channel planes R G B A, the channel
+// deltas D*, and the biased terms XR = vg_r + 8, XB = vg_b + 8, XG = vg + 32, XA = va + 16 (seqoia.h:585-590).
+// H = 0x80808080, L = 0x7f7f7f7f: literals, or VGPRs the caller keeps them in (an SGPR operand makes a fast-class
+// instruction a slow one, and the three-operand forms cannot take a literal)
+SQOA_DEV SwarGroup sqoa_ops(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uint32_t DR, uint32_t DG, uint32_t DB, uint32_t DA,
+                            uint32_t XR, uint32_t XB, uint32_t XG, uint32_t XA, uint32_t H = 0x80808080u, uint32_t L = 0x7f7f7f7fu) {
+    const uint32_t MF0 = 0xf0f0f0f0u, MC0 = 0xc0c0c0c0u, ME0 = 0xe0e0e0e0u, M0F = 0x0f0f0f0fu;
+    const uint32_t C60 = 0x60606060u, CFE = 0xfefefefeu;
+    auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
+    SwarGroup o;
+    const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
+    const uint32_t z0 = nz(DR | DG | DB | DA), z1 = nz(bad), z2 = nz(DA);
+    const uint32_t b0 = z0 >> 7, b1 = z1 >> 7, b2 = z2 >> 7;   // 1 = differs from its predecessor; needs RGB/RGBA; alpha moved
+    // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
+    const uint32_t ne_mask = (z0 - b0) | z0, raw_mask = (z1 - b1) | z1, na_mask = (z2 - b2) | z2;
+    const uint32_t L0 = XG | H;                                  // LUMA byte 0 (seqoia.h:612)
+    const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);          // LUMA byte 1 (seqoia.h:614)
+    const uint32_t L2 = (XA | C60) & na_mask;                    // ALPHA suffix (seqoia.h:617)
+    const uint32_t TG = CFE | b2;                                // RGB / RGBA tag (seqoia.h:622)
+    // the op's bytes, already chosen between LUMA[+ALPHA] and RGB[A]; zero for repeated pixels
+    o.W0 = ((L0 & ~raw_mask) | (TG & raw_mask)) & ne_mask;
+    o.W1 = ((L1 & ~raw_mask) | (R & raw_mask)) & ne_mask;
+    o.W2 = ((L2 & ~raw_mask) | (G & raw_mask)) & ne_mask;
+    o.W3 = B & raw_mask & ne_mask;
+    o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
+    o.b0 = b0;
+    o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+    return o;
+}
+
+// Channel deltas mod 256 of four pixels against their predecessors (seqoia.h:585-588) and vg_r / vg_b / vg / va with the
+// range-test bias folded in (seqoia.h:589-590, :606-611), then the op decision.
+SQOA_DEV SwarGroup sqoa_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uint32_t Rp, uint32_t Gp, uint32_t Bp, uint32_t Ap,
+                              uint32_t H, uint32_t L) {
+    const uint32_t C08 = 0x08080808u, C20 = 0x20202020u, C10 = 0x10101010u;
+    auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
+    const uint32_t DR = sub8(R, Rp), DG = sub8(G, Gp), DB = sub8(B, Bp), DA = sub8(A, Ap);
+    const uint32_t DGm = ((DG | H) - C08) ^ ((DG & H) ^ H);                 // vg - 8
+    const uint32_t XR = sub8(DR, DGm), XB = sub8(DB, DGm);                  // vg_r + 8, vg_b + 8
+    const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
+    return sqoa_ops(R, G, B, A, DR, DG, DB, DA, XR, XB, XG, XA, H, L);
+}
+
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
 template <bool QOI>
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
     // constants as literals: an SGPR operand would put the add / and / or they feed into the slow VALU class
     const uint32_t H = 0x80808080u, L = 0x7f7f7f7fu;
     const uint32_t C08 = 0x08080808u, C20 = 0x20202020u, C10 = 0x10101010u;
-    const uint32_t MF0 = 0xf0f0f0f0u, MC0 = 0xc0c0c0c0u, ME0 = 0xe0e0e0e0u, M0F = 0x0f0f0f0fu;
-    const uint32_t C60 = 0x60606060u, CFE = 0xfefefefeu;
+    const uint32_t MF0 = 0xf0f0f0f0u, MC0 = 0xc0c0c0c0u, M0F = 0x0f0f0f0fu;
+    const uint32_t CFE = 0xfefefefeu;
     auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
     auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
     uint32_t c0 = pb;  // pixel in front of the group's first row
@@ -186,23 +249,7 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
         const uint32_t XG = ((DG & L) + C20) ^ (DG & H), XA = ((DA & L) + C10) ^ (DA & H);  // vg + 32, va + 16
         SwarGroup& o = grp[g];
         if constexpr (!QOI) {
-            const uint32_t bad = ((XR | XB) & MF0) | (XG & MC0) | (XA & ME0);       // non-zero byte: LUMA does not fit (seqoia.h:606-611)
-            const uint32_t z0 = nz(DR | DG | DB | DA), z1 = nz(bad), z2 = nz(DA);
-            const uint32_t b0 = z0 >> 7, b1 = z1 >> 7, b2 = z2 >> 7;   // 1 = differs from its predecessor; needs RGB/RGBA; alpha moved
-            // 0xff where set (0x80 - 1 = 0x7f, | 0x80)
-            const uint32_t ne_mask = (z0 - b0) | z0, raw_mask = (z1 - b1) | z1, na_mask = (z2 - b2) | z2;
-            const uint32_t L0 = XG | H;                                  // LUMA byte 0 (seqoia.h:612)
-            const uint32_t L1 = ((XR << 4) & MF0) | (XB & M0F);          // LUMA byte 1 (seqoia.h:614)
-            const uint32_t L2 = (XA | C60) & na_mask;                    // ALPHA suffix (seqoia.h:617)
-            const uint32_t TG = CFE | b2;                                // RGB / RGBA tag (seqoia.h:622)
-            // the op's bytes, already chosen between LUMA[+ALPHA] and RGB[A]; zero for repeated pixels
-            o.W0 = ((L0 & ~raw_mask) | (TG & raw_mask)) & ne_mask;
-            o.W1 = ((L1 & ~raw_mask) | (R & raw_mask)) & ne_mask;
-            o.W2 = ((L2 & ~raw_mask) | (G & raw_mask)) & ne_mask;
-            o.W3 = B & raw_mask & ne_mask;
-            o.AH = A & na_mask & raw_mask;                   // 5th byte of RGBA
-            o.b0 = b0;
-            o.Nn = (((b0 & b1) + b0) << 1) + (b0 & b2);      // bytes per pixel: 2/3 LUMA, 4/5 RGB[A], 0 if repeated
+            o = sqoa_ops(R, G, B, A, DR, DG, DB, DA, XR, XB, XG, XA);
         } else {
             // QOI-compat ops for a pixel that missed the index (seqoia.h:573-634): alpha moved -> RGBA; else DIFF if
             // vr, vg, vb in [-2, 1]; else LUMA; else RGB
@@ -243,7 +290,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                             unsigned long long* smask) {
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
     const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
-    const uint32_t sink_addr = stage_addr + (uint32_t)ENC_STG + 4u * lane;
+    const uint32_t sink_addr = stage_addr + 4u * lane;  // a pixel that emits nothing ORs its zeros into a dword of the lane's own, anywhere in the buffer
     uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
     cr[0] = c_in;
 #pragma unroll
@@ -329,8 +376,8 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
             if (QOI && hitv[i]) { lo = hitv[i] & 63u; hi = 0; }
             const uint32_t sh = (o & 3u) * 8u;
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
-            // pixels that emit nothing send their zero to a private sink instead of being masked off: no exec juggling,
-            // and no 64 lanes OR-ing the same dword
+            // pixels that emit nothing OR their zero into a dword of the lane's own instead of being masked off: no exec
+            // juggling, and no 64 lanes OR-ing the same dword
             // (LDS addresses: the staging buffer is 16-byte aligned, so its base rides on the wave-uniform row base for free)
             lds_u32 p = (lds_u32)(uintptr_t)(n ? (o & ~3u) : sink_addr);
             __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -368,7 +415,7 @@ template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
                                                         sqoa_hip_result* __restrict__ results) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG + ENC_SINK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
     __shared__ __attribute__((aligned(16))) uint8_t s_pre[W][ENC_PRE];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
@@ -380,6 +427,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     __shared__ unsigned long long s_smask[QW][64];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
     __shared__ uint32_t s_tabtag[2][W];
+    // L8 path: run bytes of the 8 consecutive pixels a lane owns, by their 8 "repeats its predecessor" flags: byte j =
+    // 0xc0 | (c - 1) where c = repeated pixels ending at pixel j inside the lane (the byte a run flushes as when it ends
+    // there and began inside the lane, seqoia.h:554-561), 0 where pixel j does not repeat
+    __shared__ __attribute__((aligned(8))) uint32_t s_runtab[QOI ? 1 : 256][2];
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
@@ -399,7 +450,19 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     uint8_t* stage = s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; }
-    for (uint32_t i = lane * 16u; i < (uint32_t)(ENC_STG + ENC_SINK); i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    if constexpr (!QOI) {
+        for (uint32_t e8 = threadIdx.x; e8 < 256u; e8 += W * 64) {
+            unsigned long long v = 0;
+            uint32_t c = 0;
+            for (int k = 0; k < 8; ++k) {
+                c = (e8 >> k) & 1u ? c + 1u : 0u;
+                if (c) v |= (unsigned long long)(0xbfu + c) << (8 * k);
+            }
+            s_runtab[e8][0] = (uint32_t)v;
+            s_runtab[e8][1] = (uint32_t)(v >> 32);
+        }
+    }
     __syncthreads();
 
     if (w == 0 && (uint32_t)lane < hdr_len) {  // seqoia.h:497-514
@@ -487,10 +550,17 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         }
     };
 
+    // L8 layout (below): the lane's eight consecutive pixels instead of one pixel of each row
+    auto take8 = [&](uint32_t (&px)[ENC_S]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
+        px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+    };
+
     // One sub-tile.  SW (compile time) = the SWAR path: colour image, sub-tile fully inside the image.  The loop over the
     // full sub-tiles of a colour image is instantiated with SW = true only, so the generic one-row-per-step code (mono
     // images, the partial sub-tile at the end of an image) stays out of the hot loop.
-    auto body = [&](auto sw_tag, auto mid_tag, uint32_t j, bool more) {
+    auto body = [&](auto sw_tag, auto mid_tag, uint32_t j, bool more, bool next8 = false) {
         constexpr bool SW = decltype(sw_tag)::value;
         constexpr int KIND = decltype(mid_tag)::value;   // 0: general; 1 / 2: hot-loop instance (2: 4-byte pixels known)
         constexpr bool MID = KIND != 0;                   // j > 0, full sub-tiles follow, `more` is true: no edge cases in this instance
@@ -702,7 +772,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's before the stores of the flush join the memory queue
         if (more) {
-            take(cur, KIND == 2 ? false : nxt_raw3);
+            if (next8) take8(cur); else take(cur, KIND == 2 ? false : nxt_raw3);
             cur_pb = nxt_pb.value();
             cur_pa = nxt_pa.value();
         }
@@ -724,6 +794,178 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         }
     };
 
+
+    // ---- L8: every lane owns EIGHT CONSECUTIVE pixels of the sub-tile (SQOA colour images, 4-byte pixels, hot loop) ----------------
+    // The row layout above pays per 64-pixel row: a ballot, run bookkeeping from 64-bit lane masks, a DPP prefix sum, the
+    // lane-0 fix of the predecessor planes.  With eight consecutive pixels per lane the predecessor of 7 pixels out of 8 is
+    // in the lane's own registers (a byte shift of the channel planes), runs shorter than the lane's stretch are a table
+    // look-up on the lane's 8 repeat flags, and the byte offsets are one in-register prefix per four pixels plus ONE wave
+    // scan per sub-tile.  Runs that cross lanes (flat areas) take a per-lane fix-up behind a wave-uniform branch.
+    auto body8 = [&](uint32_t j, bool next8) {
+        if constexpr (!QOI) {
+        typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+        __builtin_assume(j > 0);
+        NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
+        bool nxt_raw3 = false;
+        fetch(std::integral_constant<int, 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
+        const uint32_t pb = cur_pb, pa = cur_pa;
+        uint32_t dif = 0;
+#pragma unroll
+        for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+        asm volatile("" : "+v"(dif));
+        const bool flat = __ballot(dif != 0u) == 0ull;
+        unsigned long long* my_run = &s_run[(j / W) & 1][w];
+        unsigned long long* prev_run = &s_run[((j - 1) / W) & 1][(j - 1) % W];
+        uint32_t sbase = 0;
+        if (flat) {
+            const uint32_t c_in = chain_wait(prev_run, j, st);
+            chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
+            // k runs over c_in+1 .. c_in+512: exactly one of them is a multiple of 512 (0xfd, seqoia.h:546-549); the
+            // last pixel additionally owns the flush (seqoia.h:554-561)
+            const uint32_t r0 = c_in & 511u;
+            unsigned long long v = 0xfdull;
+            uint32_t nbytes = 1, b9 = 0;
+            if (r0 != 0u && pa != pb) {
+                const uint32_t q = ((r0 - 1u) * 1075u) >> 16;
+                const uint32_t last = 0xc0u | (r0 - 1u - 61u * q);
+                const unsigned long long fc = 0xfcfcfcfcfcfcfcfcull;
+                const unsigned long long f = q >= 7 ? fc : ((fc & ((1ull << (8u * q)) - 1ull)) | (unsigned long long)last << (8u * q));
+                v |= f << 8;
+                if (q >= 7) b9 = q == 7 ? last : (0xfcu | last << 8);
+                nbytes = q + 2u;
+            }
+            if (lane == 0) {
+                reinterpret_cast<uint32_t*>(stage)[0] = (uint32_t)v;
+                reinterpret_cast<uint32_t*>(stage)[1] = (uint32_t)(v >> 32);
+                reinterpret_cast<uint32_t*>(stage)[2] = b9;
+            }
+            sbase = nbytes;
+        } else {
+            const uint32_t ONE = 0x01010101u;
+            uint32_t Hv, L7;  // the two SWAR constants in VGPRs
+            asm volatile("v_mov_b32 %0, 0x80808080" : "=v"(Hv));
+            asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(L7));
+            // channel planes of my two groups of four pixels (byte i = pixel 4g + i)
+            uint32_t R0, G0, B0, A0, R1, G1, B1, A1;
+            {
+                const uint32_t a01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x07030602u);
+                const uint32_t a23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x07030602u);
+                R0 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G0 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+                B0 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A0 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+            }
+            {
+                const uint32_t a01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x07030602u);
+                const uint32_t a23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x07030602u);
+                R1 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G1 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+                B1 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A1 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+            }
+            const uint32_t last_px = bcast_lane(cur[ENC_S - 1], 63);
+            // predecessor planes: a byte shift inside the lane; the first pixel takes the lane below's last one (lane 0: pb)
+            const uint32_t qR = shift_up1(R1, pb << 24), qG = shift_up1(G1, (pb << 16) & 0xff000000u),
+                           qB = shift_up1(B1, (pb << 8) & 0xff000000u), qA = shift_up1(A1, pb & 0xff000000u);
+            const SwarGroup g0 = sqoa_group(R0, G0, B0, A0, __builtin_amdgcn_alignbyte(R0, qR, 3), __builtin_amdgcn_alignbyte(G0, qG, 3),
+                                            __builtin_amdgcn_alignbyte(B0, qB, 3), __builtin_amdgcn_alignbyte(A0, qA, 3), Hv, L7);
+            const SwarGroup g1 = sqoa_group(R1, G1, B1, A1, __builtin_amdgcn_alignbyte(R1, R0, 3), __builtin_amdgcn_alignbyte(G1, G0, 3),
+                                            __builtin_amdgcn_alignbyte(B1, B0, 3), __builtin_amdgcn_alignbyte(A1, A0, 3), Hv, L7);
+            // ---- runs (seqoia.h:544-561): e = 1 where a pixel repeats its predecessor, l = 1 where a run ends
+            const uint32_t e0 = g0.b0 ^ ONE, e1 = g1.b0 ^ ONE;
+            const uint32_t e0n = shift_down1(e0, pa == last_px ? 1u : 0u);  // the lane above's first four flags; lane 63: the pixel after the sub-tile
+            const uint32_t l0 = e0 & ~__builtin_amdgcn_alignbyte(e1, e0, 1), l1 = e1 & ~__builtin_amdgcn_alignbyte(e0n, e1, 1);
+            const uint32_t E8 = __builtin_amdgcn_udot4(e1, 0x80402010u, __builtin_amdgcn_udot4(e0, 0x08040201u, 0u, false), false);
+            const uint32_t rt0 = s_runtab[E8][0], rt1 = s_runtab[E8][1];
+            uint32_t W00 = g0.W0 | (rt0 & ((l0 + L7) ^ L7)), W01 = g1.W0 | (rt1 & ((l1 + L7) ^ L7));
+            uint32_t Nn0 = g0.Nn + l0, Nn1 = g1.Nn + l1;
+            // the sub-tile's trailing run, published before anything is waited for
+            const unsigned long long allq = __ballot(E8 == 0xffu);   // lanes whose eight pixels all repeat (never all 64: not flat)
+            const uint32_t tzl = (uint32_t)__builtin_clzll(~allq);
+            const uint32_t Ea = (uint32_t)__builtin_amdgcn_readlane((int)E8, (int)(63u - tzl));
+            chain_post(my_run, j + 1, 8u * tzl + (uint32_t)__builtin_clz((~Ea << 24) | 0x00800000u), lane);
+            uint32_t big = 0, big_at = 0;  // run remainder >= 62 (seqoia.h:555-559): q << 8 | last byte, and the pixel that owns it
+            if (__ballot((e0 & 1u) != 0u) != 0ull) {
+                // some lane starts inside a run: its leading repeats continue a run of `carry` pixels in front of the lane
+                const uint32_t c_in = (bcast_first(e0) & 1u) ? chain_wait(prev_run, j, st) : 0u;
+                const uint32_t nE = ~E8;
+                const uint32_t f = (e0 & 1u) ? (uint32_t)__builtin_ctz(nE) : 0u;                 // leading repeats, 0..8
+                const uint32_t t = (uint32_t)__builtin_clz((nE << 24) | 0x00800000u);            // trailing repeats, 0..8
+                const unsigned long long below = ~allq & ((1ull << lane) - 1ull);                 // lanes below me that are not one solid run
+                const int anchor = below ? 63 - __builtin_clzll(below) : 0;
+                const uint32_t t_anchor = (uint32_t)__builtin_amdgcn_ds_bpermute(anchor << 2, (int)t);
+                const uint32_t carry = below ? 8u * ((uint32_t)lane - 1u - (uint32_t)anchor) + t_anchor : 8u * (uint32_t)lane + c_in;
+                const uint32_t pe = (f - 1u) & 7u;                                               // where my leading run ends, if it ends in my stretch
+                const uint32_t lbits = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
+                const bool ends = f != 0u && ((lbits >> pe) & 1u);
+                const uint32_t r = (carry + f) & 511u;
+                const uint32_t q = ((r - 1u) * 1075u) >> 16;                                     // (r - 1) / 61 for 1 <= r <= 511
+                const uint32_t lastb = 0xc0u | (r - 1u - 61u * q);
+                auto setb = [&](uint32_t& x0, uint32_t& x1, uint32_t px_i, uint32_t val, bool on) {
+                    const uint32_t sh = (px_i & 3u) * 8u, m = on ? 0xffu << sh : 0u, v = val << sh;
+                    if (px_i < 4u) x0 = (x0 & ~m) | (v & m); else x1 = (x1 & ~m) | (v & m);
+                };
+                // the run ends here: flush of the true remainder (the table only knows the repeats inside my stretch), or 0xfd
+                // where the remainder is 0 (the pixel itself is the 512th, seqoia.h:546-549)
+                setb(W00, W01, pe, r == 0u ? 0xfdu : q == 0u ? lastb : 0u, ends);
+                setb(Nn0, Nn1, pe, r == 0u ? 1u : q + 1u, ends);
+                if (ends && r != 0u && q != 0u) { big = q << 8 | lastb; big_at = pe; }
+                // every 512th pixel of the run
+                const uint32_t jfd = 511u - (carry & 511u);
+                const bool hasfd = f != 0u && jfd < f;
+                setb(W00, W01, jfd & 7u, 0xfdu, hasfd);
+                setb(Nn0, Nn1, jfd & 7u, 1u, hasfd);
+            }
+            // ---- byte offsets: prefix inside the lane, one scan across the wave
+            uint32_t P0, P1;   // (written out: the compiler turns x + (x << 8) + ... into a v_mul_lo_u32)
+            asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(P0) : "v"(Nn0));
+            asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(P1) : "v"(Nn1));
+            asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(P0) : "v"(P0));
+            asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(P1) : "v"(P1));
+            const uint32_t T0 = P0 >> 24, T = T0 + (P1 >> 24);
+            const uint32_t incl = wave_incl_scan(T);
+            sbase = bcast_lane(incl, 63);
+            const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
+            // a lane without bytes ORs its zeros into a dword of its own (no 64 lanes on one LDS word in flat stretches)
+            const uint32_t lb0 = T ? stage_addr + incl - T : stage_addr + 4u * lane, lb1 = lb0 + T0;
+            const uint32_t X0 = P0 - Nn0, X1 = P1 - Nn1;   // exclusive prefixes, one byte per pixel
+            // back from byte planes to one dword per pixel, shifted to its byte address and OR-ed into the staging buffer
+            auto emit4 = [&](uint32_t w0, const SwarGroup& G, uint32_t X, uint32_t lb) {
+                const uint32_t w01 = __builtin_amdgcn_perm(G.W1, w0, 0x05010400u), w23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x05010400u);
+                const uint32_t u01 = __builtin_amdgcn_perm(G.W1, w0, 0x07030602u), u23 = __builtin_amdgcn_perm(G.W3, G.W2, 0x07030602u);
+                const uint32_t lo4[4] = {__builtin_amdgcn_perm(w23, w01, 0x05040100u), __builtin_amdgcn_perm(w23, w01, 0x07060302u),
+                                         __builtin_amdgcn_perm(u23, u01, 0x05040100u), __builtin_amdgcn_perm(u23, u01, 0x07060302u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t o = lb + ((X >> (8 * i)) & 255u);
+                    const uint32_t hi = (G.AH >> (8 * i)) & 255u;
+                    const unsigned long long v = ((unsigned long long)hi << 32 | lo4[i]) << ((o & 3u) * 8u);
+                    lds_u32 p = (lds_u32)(uintptr_t)(o & ~3u);
+                    __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            };
+            emit4(W00, g0, X0, lb0);
+            emit4(W01, g1, X1, lb1);
+            if (__ballot(big != 0u) != 0ull) {  // q x 0xfc, then the last byte (rare)
+                if (big) {
+                    const uint32_t q = big >> 8, last = big & 255u;
+                    const uint32_t ob0 = (big_at < 4u ? lb0 + ((X0 >> (8u * big_at)) & 255u) : lb1 + ((X1 >> (8u * (big_at & 3u))) & 255u));
+#pragma nounroll
+                    for (uint32_t tt = 0; tt <= q; ++tt) {
+                        const uint32_t ob = ob0 + tt;
+                        __hip_atomic_fetch_or((lds_u32)(uintptr_t)(ob & ~3u), (tt == q ? last : 0xfcu) << ((ob & 3u) * 8u),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+        }
+        // this sub-tile's pixels are dead: pick up the next one's
+        if (next8) take8(cur); else take(cur, false);
+        cur_pb = nxt_pb.value();
+        cur_pa = nxt_pa.value();
+        const uint32_t pos = chain_wait(&s_pos[(j - 1) % W], j, st);
+        chain_post(&s_pos[w], j + 1, pos + sbase, lane);
+        flush_stage(stage, sbase, dst + pos, lane);
+        }
+    };
+
     const uint32_t nfull = N / ENC_SUB;  // sub-tiles that lie fully inside the image
     if (!mono) {
         uint32_t j = w;
@@ -739,8 +981,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         __builtin_amdgcn_s_setprio(3);
         // MID instance of the body: not the wave's first sub-tile (j > 0), a full sub-tile behind it, and another one of this
         // wave's to prefetch (j + W < nfull - 1 ... all three known at compile time); the few others take the general instance
-        if (j < nfull) { body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull); j += W; }
         const uint32_t nmid = nfull > (uint32_t)W + 1u ? nfull - (uint32_t)W - 1u : 0u;  // j + W is interior as well
+#if !defined(SQOA_ENC_L8) || SQOA_ENC_L8
+        const bool l8 = !QOI && ch == 4 && (job.src & 3ull) == 0;  // the hot loop of SQOA colour images with dword pixels runs the L8 body
+#else
+        const bool l8 = false;
+#endif
+        if (j < nfull) { body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull, l8 && j + W < nmid); j += W; }
         auto hot_loop = [&](auto kind_tag) {
             for (; j < nmid; j += W) {
                 if (j >= thr) {
@@ -752,7 +999,17 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 body(std::true_type{}, kind_tag, j, true);
             }
         };
-        if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
+        if (l8) {
+            for (; j < nmid; j += W) {
+                if (j >= thr) {
+                    ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
+                    if (q == 1) __builtin_amdgcn_s_setprio(2);
+                    else if (q == 2) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                body8(j, j + W < nmid);
+            }
+        } else if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
         else hot_loop(std::integral_constant<int, 1>{});
         for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
