@@ -174,6 +174,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #define DPHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#elif defined(SQOA_ASM_MARK)  // phase markers as comments in the assembly (tools/asm_cost.py by region)
+#define DPHASE(k) asm volatile("; SQOA_PHASE " #k)
 #else
 #define DPHASE(k) do { } while (0)
 #endif
@@ -350,8 +352,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     const uint32_t m = meta[i], am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
                     gptr32 o = (gptr32)out + lane_p + (m & 0x1fffu);
+#ifdef SQOA_DBG_DEC_NOSTORE  // timing experiments only
+                    asm volatile("" :: "v"(o), "v"(v), "v"(m));
+#else
                     if (m >> 13) o[0] = v;
                     if (m >> 14) o[1] = v;  // cnt == 2: a literal op and the one-pixel run behind it
+#endif
                 }
             } else {
             auto store_ops = [&](auto oc_tag) {

@@ -132,7 +132,12 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     for (int k = 0; k < (ENC_STG + 1023) / 1024; ++k) {
         const uint32_t u = (uint32_t)lane + 64u * k;
         if (u < nb) {
+#ifdef SQOA_DBG_NOSTORE
+            u32x4 vv = *reinterpret_cast<const u32x4*>(stage + 16u * u);
+            asm volatile("" :: "v"(vv), "v"(g));
+#else
             ((gptr128u)g)[u] = *reinterpret_cast<const u32x4*>(stage + 16u * u);
+#endif
             *reinterpret_cast<uint4*>(stage + 16u * u) = zero;
         }
     }
@@ -482,6 +487,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #ifdef SQOA_TRACE
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #define PHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#elif defined(SQOA_ASM_MARK)
+#define PHASE(k) asm volatile("; SQOA_PHASE " #k)
 #else
 #define PHASE(k) do { } while (0)
 #endif
@@ -551,10 +558,17 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     };
 
     // L8 layout (below): the lane's eight consecutive pixels instead of one pixel of each row
-    auto take8 = [&](uint32_t (&px)[ENC_S]) {
+    // (3-byte pixels: the lane's 24 bytes as they lie, px[0..5]; the channel planes are gathered from them directly)
+    auto take8 = [&](uint32_t (&px)[ENC_S], bool raw3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
-        px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+        if (raw3) {
+            const uint2 a = *reinterpret_cast<const uint2*>(pre + 24 * lane), b = *reinterpret_cast<const uint2*>(pre + 24 * lane + 8),
+                        c = *reinterpret_cast<const uint2*>(pre + 24 * lane + 16);
+            px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y; px[6] = 0; px[7] = 0;
+        } else {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
+            px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+        }
     };
 
     // One sub-tile.  SW (compile time) = the SWAR path: colour image, sub-tile fully inside the image.  The loop over the
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's before the stores of the flush join the memory queue
         if (more) {
-            if (next8) take8(cur); else take(cur, KIND == 2 ? false : nxt_raw3);
+            if (next8) take8(cur, KIND == 2 ? false : nxt_raw3); else take(cur, KIND == 2 ? false : nxt_raw3);
             cur_pb = nxt_pb.value();
             cur_pa = nxt_pa.value();
         }
@@ -801,17 +815,36 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // in the lane's own registers (a byte shift of the channel planes), runs shorter than the lane's stretch are a table
     // look-up on the lane's 8 repeat flags, and the byte offsets are one in-register prefix per four pixels plus ONE wave
     // scan per sub-tile.  Runs that cross lanes (flat areas) take a per-lane fix-up behind a wave-uniform branch.
-    auto body8 = [&](uint32_t j, bool next8) {
+    auto body8 = [&](auto px3_tag, uint32_t j, bool next8) {
+        constexpr bool PX3 = decltype(px3_tag)::value;  // 3-byte pixels: cur[0..5] hold the lane's 24 bytes
         if constexpr (!QOI) {
         typedef __attribute__((address_space(3))) uint32_t* lds_u32;
         __builtin_assume(j > 0);
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
-        fetch(std::integral_constant<int, 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
+        fetch(std::integral_constant<int, PX3 ? 1 : 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
         const uint32_t pb = cur_pb, pa = cur_pa;
-        uint32_t dif = 0;
+        // channel planes of my two groups of four pixels (byte i = pixel 4g + i)
+        uint32_t R0, G0, B0, A0, R1, G1, B1, A1;
+        uint32_t dif;
+        if constexpr (PX3) {
+            // d0 = r0 g0 b0 r1, d1 = g1 b1 r2 g2, d2 = b2 r3 g3 b3: every plane takes bytes of all three dwords
+            auto gather3 = [&](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t& R, uint32_t& G, uint32_t& B) {
+                R = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
+                G = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
+                B = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
+            };
+            gather3(cur[0], cur[1], cur[2], R0, G0, B0);
+            gather3(cur[3], cur[4], cur[5], R1, G1, B1);
+            A0 = A1 = 0xffffffffu;
+            const uint32_t m = 0x01010101u;
+            dif = (R0 ^ (pb & 255u) * m) | (G0 ^ ((pb >> 8) & 255u) * m) | (B0 ^ ((pb >> 16) & 255u) * m) |
+                  (R1 ^ (pb & 255u) * m) | (G1 ^ ((pb >> 8) & 255u) * m) | (B1 ^ ((pb >> 16) & 255u) * m);
+        } else {
+            dif = 0;
 #pragma unroll
-        for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+            for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+        }
         asm volatile("" : "+v"(dif));
         const bool flat = __ballot(dif != 0u) == 0ull;
         unsigned long long* my_run = &s_run[(j / W) & 1][w];
@@ -845,21 +878,22 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             uint32_t Hv, L7;  // the two SWAR constants in VGPRs
             asm volatile("v_mov_b32 %0, 0x80808080" : "=v"(Hv));
             asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(L7));
-            // channel planes of my two groups of four pixels (byte i = pixel 4g + i)
-            uint32_t R0, G0, B0, A0, R1, G1, B1, A1;
-            {
-                const uint32_t a01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x07030602u);
-                const uint32_t a23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x07030602u);
-                R0 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G0 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
-                B0 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A0 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+            if constexpr (!PX3) {
+                {
+                    const uint32_t a01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[1], cur[0], 0x07030602u);
+                    const uint32_t a23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[3], cur[2], 0x07030602u);
+                    R0 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G0 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+                    B0 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A0 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+                }
+                {
+                    const uint32_t a01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x07030602u);
+                    const uint32_t a23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x07030602u);
+                    R1 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G1 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+                    B1 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A1 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+                }
             }
-            {
-                const uint32_t a01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x05010400u), b01 = __builtin_amdgcn_perm(cur[5], cur[4], 0x07030602u);
-                const uint32_t a23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x05010400u), b23 = __builtin_amdgcn_perm(cur[7], cur[6], 0x07030602u);
-                R1 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); G1 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
-                B1 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); A1 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
-            }
-            const uint32_t last_px = bcast_lane(cur[ENC_S - 1], 63);
+            // the sub-tile's last pixel (wave-uniform), for the repeat flag of the pixel behind the sub-tile
+            const uint32_t last_px = PX3 ? bcast_lane((R1 >> 24) | ((G1 >> 24) << 8) | ((B1 >> 24) << 16) | 0xff000000u, 63) : bcast_lane(cur[ENC_S - 1], 63);
             // predecessor planes: a byte shift inside the lane; the first pixel takes the lane below's last one (lane 0: pb)
             const uint32_t qR = shift_up1(R1, pb << 24), qG = shift_up1(G1, (pb << 16) & 0xff000000u),
                            qB = shift_up1(B1, (pb << 8) & 0xff000000u), qA = shift_up1(A1, pb & 0xff000000u);
@@ -937,8 +971,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     const uint32_t hi = (G.AH >> (8 * i)) & 255u;
                     const unsigned long long v = ((unsigned long long)hi << 32 | lo4[i]) << ((o & 3u) * 8u);
                     lds_u32 p = (lds_u32)(uintptr_t)(o & ~3u);
+#ifdef SQOA_DBG_NOEMIT  // timing experiments only: the bytes are computed but not staged
+                    asm volatile("" :: "v"(p), "v"((uint32_t)v), "v"((uint32_t)(v >> 32)));
+#else
                     __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
                 }
             };
             emit4(W00, g0, X0, lb0);
@@ -957,12 +995,14 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             }
         }
         // this sub-tile's pixels are dead: pick up the next one's
-        if (next8) take8(cur); else take(cur, false);
+        if (next8) take8(cur, PX3); else take(cur, PX3);
         cur_pb = nxt_pb.value();
         cur_pa = nxt_pa.value();
         const uint32_t pos = chain_wait(&s_pos[(j - 1) % W], j, st);
         chain_post(&s_pos[w], j + 1, pos + sbase, lane);
+#ifndef SQOA_DBG_NOFLUSH
         flush_stage(stage, sbase, dst + pos, lane);
+#endif
         }
     };
 
@@ -983,7 +1023,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         // wave's to prefetch (j + W < nfull - 1 ... all three known at compile time); the few others take the general instance
         const uint32_t nmid = nfull > (uint32_t)W + 1u ? nfull - (uint32_t)W - 1u : 0u;  // j + W is interior as well
 #if !defined(SQOA_ENC_L8) || SQOA_ENC_L8
-        const bool l8 = !QOI && ch == 4 && (job.src & 3ull) == 0;  // the hot loop of SQOA colour images with dword pixels runs the L8 body
+        const bool l8 = !QOI && (ch == 3 || (ch == 4 && (job.src & 3ull) == 0));  // the hot loop of SQOA colour images runs the L8 body (4-byte pixels: dword-aligned)
 #else
         const bool l8 = false;
 #endif
@@ -999,18 +1039,25 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 body(std::true_type{}, kind_tag, j, true);
             }
         };
-        if (l8) {
-            for (; j < nmid; j += W) {
-                if (j >= thr) {
-                    ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
-                    if (q == 1) __builtin_amdgcn_s_setprio(2);
-                    else if (q == 2) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
+        if constexpr (!QOI) {
+            // SQOA: the hot loop is the L8 body; 4-byte pixels at an address that is not dword-aligned (rare) stay on the general one
+            auto loop8 = [&](auto px3_tag) {
+                for (; j < nmid; j += W) {
+                    if (j >= thr) {
+                        ++q; thr = q == 1 ? thr2 : q == 2 ? thr3 : ~0u;
+                        if (q == 1) __builtin_amdgcn_s_setprio(2);
+                        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                    body8(px3_tag, j, j + W < nmid);
                 }
-                body8(j, j + W < nmid);
-            }
-        } else if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
-        else hot_loop(std::integral_constant<int, 1>{});
+            };
+            if (l8 && ch == 4) loop8(std::false_type{});
+            else if (l8) loop8(std::true_type{});
+        } else {
+            if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
+            else hot_loop(std::integral_constant<int, 1>{});
+        }
         for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
         for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);

@@ -385,3 +385,56 @@ def test_repeated_launches_are_bit_identical(sq, orc, mode):
         dec.launch()
         assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, px)
     dec.close(); enc.close()
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+def test_l8_hot_loop_runs_of_every_length(sq, orc, ch):
+    """The hot loop of colour images gives every lane eight consecutive pixels; runs then start, end and cross the 512th
+    repeat at every position inside a lane, across lanes and across sub-tiles (seqoia.h:544-561).  Images large enough
+    that nearly all sub-tiles take that loop, filled with runs of random lengths (1 .. 1400, dense around the 61 / 62 /
+    511 / 512 boundaries) separated by one to three literal pixels of every op kind."""
+    import torch
+
+    rng = np.random.default_rng(1234 + ch)
+    o = orc.best()
+    w, h, n = 512, 160, 6
+    imgs = []
+    for k in range(n):
+        px = np.zeros((w * h, ch), dtype=np.uint8)
+        p = 0
+        cur = rng.integers(0, 256, size=ch)
+        while p < w * h:
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                ln = int(rng.integers(1, 10))
+            elif kind == 1:
+                ln = int(rng.choice([60, 61, 62, 63, 64, 122, 123, 124, 510, 511, 512, 513, 514, 1023, 1024, 1025])) + int(rng.integers(-1, 2))
+            elif kind == 2:
+                ln = int(rng.integers(1, 1400))
+            else:
+                ln = int(rng.integers(1, 70))
+            px[p:p + ln] = cur
+            p += ln
+            for _ in range(int(rng.integers(1, 4))):  # literals: small delta (LUMA), alpha step (ALPHA suffix), jump (RGB / RGBA)
+                if p >= w * h:
+                    break
+                t = rng.integers(0, 4)
+                if t == 0:
+                    cur = (cur + rng.integers(-3, 4, size=ch)) % 256
+                elif t == 1 and ch == 4:
+                    cur = cur.copy(); cur[3] = (cur[3] + rng.integers(-16, 16)) % 256
+                elif t == 2 and ch == 4:
+                    cur = rng.integers(0, 256, size=ch)
+                else:
+                    cur = cur.copy(); cur[:3] = rng.integers(0, 256, size=3)
+                px[p] = cur
+                p += 1
+        imgs.append(px.reshape(-1))
+    t = torch.from_numpy(np.stack(imgs).reshape(n, h, w, ch)).cuda()
+    plan = sq.EncodePlan(t, qoi_compat=0)
+    plan.launch()
+    assert (plan.results()["status"] == 0).all()
+    for k, s in enumerate(plan.streams()):
+        want = o.encode(imgs[k], w, h, ch, 0)
+        assert s == want, (ch, k, len(s), len(want), next((i for i in range(min(len(s), len(want))) if s[i] != want[i]), None))
+    plan.close()
