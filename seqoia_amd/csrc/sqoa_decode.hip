@@ -522,13 +522,19 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
 
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
                                               sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
-// Wave-parallel SQOA kernel first; whatever it marks SQOA_HIP_ST_SLOWPATH goes through the fallback kernel.
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+// Wave-parallel SQOA kernel first; what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
+// streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel.
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipError_t e = sqoa_launch_decode_wave(d_jobs, d_ids, n, d_results, stream);
     if (e != hipSuccess) return e;
+#if !defined(SQOA_QDEC) || SQOA_QDEC
+    e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
+    if (e != hipSuccess) return e;
+#endif
     hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(128), 0, stream, d_jobs, d_ids, d_results, 1);
     return hipGetLastError();
 }

@@ -15,7 +15,7 @@
 
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 
 static thread_local char g_err[256] = "";
@@ -41,6 +41,7 @@ struct sqoa_hip_plan {
     sqoa_hip_result* d_init = nullptr;  // results as they must read before a launch (BADARG rows pre-filled)
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
+    int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;       // recorded behind the kernels of the most recent launch, on whatever stream it used
@@ -132,6 +133,11 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             ids_a.push_back(i);
         }
     }
+    if (p->kind == SQOA_HIP_DECODE) {
+        unsigned long long bytes = 0;
+        for (int i : ids_a) bytes += jobs[i].src_size;
+        p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
+    }
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
     p->n_qoi = (int)ids_b.size();
@@ -202,7 +208,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids, p->n_sqoa, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }
