@@ -822,7 +822,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         __builtin_assume(j > 0);
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
+        PHASE(7);
         fetch(std::integral_constant<int, PX3 ? 1 : 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
+        PHASE(0);
         const uint32_t pb = cur_pb, pa = cur_pa;
         // channel planes of my two groups of four pixels (byte i = pixel 4g + i)
         uint32_t R0, G0, B0, A0, R1, G1, B1, A1;
@@ -909,43 +911,52 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             const uint32_t rt0 = s_runtab[E8][0], rt1 = s_runtab[E8][1];
             uint32_t W00 = g0.W0 | (rt0 & ((l0 + L7) ^ L7)), W01 = g1.W0 | (rt1 & ((l1 + L7) ^ L7));
             uint32_t Nn0 = g0.Nn + l0, Nn1 = g1.Nn + l1;
+            PHASE(1);
             // the sub-tile's trailing run, published before anything is waited for
             const unsigned long long allq = __ballot(E8 == 0xffu);   // lanes whose eight pixels all repeat (never all 64: not flat)
             const uint32_t tzl = (uint32_t)__builtin_clzll(~allq);
             const uint32_t Ea = (uint32_t)__builtin_amdgcn_readlane((int)E8, (int)(63u - tzl));
             chain_post(my_run, j + 1, 8u * tzl + (uint32_t)__builtin_clz((~Ea << 24) | 0x00800000u), lane);
             uint32_t big = 0, big_at = 0;  // run remainder >= 62 (seqoia.h:555-559): q << 8 | last byte, and the pixel that owns it
+#ifdef SQOA_DBG_NOCARRY
+            if (false) {
+#else
             if (__ballot((e0 & 1u) != 0u) != 0ull) {
+#endif
                 // some lane starts inside a run: its leading repeats continue a run of `carry` pixels in front of the lane
                 const uint32_t c_in = (bcast_first(e0) & 1u) ? chain_wait(prev_run, j, st) : 0u;
                 const uint32_t nE = ~E8;
-                const uint32_t f = (e0 & 1u) ? (uint32_t)__builtin_ctz(nE) : 0u;                 // leading repeats, 0..8
+                const uint32_t f = (uint32_t)__builtin_ctz(nE);                                   // leading repeats, 0..8 (bit 8 of ~E8 is set)
                 const uint32_t t = (uint32_t)__builtin_clz((nE << 24) | 0x00800000u);            // trailing repeats, 0..8
                 const unsigned long long below = ~allq & ((1ull << lane) - 1ull);                 // lanes below me that are not one solid run
                 const int anchor = below ? 63 - __builtin_clzll(below) : 0;
                 const uint32_t t_anchor = (uint32_t)__builtin_amdgcn_ds_bpermute(anchor << 2, (int)t);
                 const uint32_t carry = below ? 8u * ((uint32_t)lane - 1u - (uint32_t)anchor) + t_anchor : 8u * (uint32_t)lane + c_in;
-                const uint32_t pe = (f - 1u) & 7u;                                               // where my leading run ends, if it ends in my stretch
-                const uint32_t lbits = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
-                const bool ends = f != 0u && ((lbits >> pe) & 1u);
+                // my leading run ends in my stretch iff a pixel of mine follows it, or (all eight repeat) the pixel after my last does not
+                const bool ends = (f - 1u < 7u) || (f == 8u && (l1 >> 24) != 0u);
                 const uint32_t r = (carry + f) & 511u;
                 const uint32_t q = ((r - 1u) * 1075u) >> 16;                                     // (r - 1) / 61 for 1 <= r <= 511
                 const uint32_t lastb = 0xc0u | (r - 1u - 61u * q);
-                auto setb = [&](uint32_t& x0, uint32_t& x1, uint32_t px_i, uint32_t val, bool on) {
-                    const uint32_t sh = (px_i & 3u) * 8u, m = on ? 0xffu << sh : 0u, v = val << sh;
-                    if (px_i < 4u) x0 = (x0 & ~m) | (v & m); else x1 = (x1 & ~m) | (v & m);
+                // one byte of the (W0, Nn) planes of my eight pixels replaced (per 32-bit half: the same through 64-bit values
+                // measured 12 % slower on the whole kernel)
+                auto patch = [&](uint32_t px_i, uint32_t w0b, uint32_t nb, bool on) {
+                    const uint32_t sh = (px_i & 3u) * 8u, m = (on ? 0xffu : 0u) << sh;
+                    const uint32_t m0 = px_i < 4u ? m : 0u, m1 = px_i < 4u ? 0u : m;
+                    const uint32_t wv = w0b << sh, nv = nb << sh;
+                    W00 = (W00 & ~m0) | (wv & m0); W01 = (W01 & ~m1) | (wv & m1);
+                    Nn0 = (Nn0 & ~m0) | (nv & m0); Nn1 = (Nn1 & ~m1) | (nv & m1);
                 };
                 // the run ends here: flush of the true remainder (the table only knows the repeats inside my stretch), or 0xfd
                 // where the remainder is 0 (the pixel itself is the 512th, seqoia.h:546-549)
-                setb(W00, W01, pe, r == 0u ? 0xfdu : q == 0u ? lastb : 0u, ends);
-                setb(Nn0, Nn1, pe, r == 0u ? 1u : q + 1u, ends);
+                const uint32_t pe = (f - 1u) & 7u;
+                patch(pe, r == 0u ? 0xfdu : q == 0u ? lastb : 0u, r == 0u ? 1u : q + 1u, ends);
                 if (ends && r != 0u && q != 0u) { big = q << 8 | lastb; big_at = pe; }
-                // every 512th pixel of the run
+                // every 512th pixel of the run (rare)
                 const uint32_t jfd = 511u - (carry & 511u);
-                const bool hasfd = f != 0u && jfd < f;
-                setb(W00, W01, jfd & 7u, 0xfdu, hasfd);
-                setb(Nn0, Nn1, jfd & 7u, 1u, hasfd);
+                const bool hasfd = jfd < f;
+                if (__ballot(hasfd) != 0ull) patch(jfd & 7u, 0xfdu, 1u, hasfd);
             }
+            PHASE(2);
             // ---- byte offsets: prefix inside the lane, one scan across the wave
             uint32_t P0, P1;   // (written out: the compiler turns x + (x << 8) + ... into a v_mul_lo_u32)
             asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(P0) : "v"(Nn0));
@@ -994,15 +1005,19 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 }
             }
         }
+        PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's
         if (next8) take8(cur, PX3); else take(cur, PX3);
         cur_pb = nxt_pb.value();
         cur_pa = nxt_pa.value();
+        PHASE(4);
         const uint32_t pos = chain_wait(&s_pos[(j - 1) % W], j, st);
+        PHASE(5);
         chain_post(&s_pos[w], j + 1, pos + sbase, lane);
 #ifndef SQOA_DBG_NOFLUSH
         flush_stage(stage, sbase, dst + pos, lane);
 #endif
+        PHASE(6);
         }
     };
 
