@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "sqoa_common.h"
@@ -133,6 +134,15 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             ids_a.push_back(i);
         }
     }
+    // One workgroup per image and workgroups are dispatched in id order: the largest images first, so that a batch of mixed
+    // sizes (BASELINE.json configs[4]) does not end with one screenshot-sized image running alone (longest-processing-time-first
+    // inside the device as well as across the ranks)
+    auto weight = [&](int i) -> unsigned long long {
+        return p->kind == SQOA_HIP_ENCODE ? (unsigned long long)jobs[i].desc.width * jobs[i].desc.height : jobs[i].src_size;
+    };
+    auto heavier = [&](int a, int b) { return weight(a) > weight(b); };
+    std::stable_sort(ids_a.begin(), ids_a.end(), heavier);
+    std::stable_sort(ids_b.begin(), ids_b.end(), heavier);
     if (p->kind == SQOA_HIP_DECODE) {
         unsigned long long bytes = 0;
         for (int i : ids_a) bytes += jobs[i].src_size;
