@@ -37,7 +37,7 @@ TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x tools/bin/sqoabatc
 tools: lib $(TOOLS)
 tools/bin/%: tools/%.c include/seqoia.h include/sqoa_hip.h
 	@mkdir -p tools/bin
-	$(CC) -std=gnu99 -O2 -Wall -Iinclude $< -o $@ -L$(OUT) -lsqoa_mi355x -Wl,-rpath,'$$ORIGIN/../../$(OUT)'
+	$(CC) -std=gnu99 -O2 -Wall -Iinclude $< -o $@ -L$(OUT) -lsqoa_mi355x -lpthread -Wl,-rpath,'$$ORIGIN/../../$(OUT)'
 
 clean:
 	rm -rf $(BUILD) $(OUT)/*.so tools/bin

@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (QOI-compat, icon sets)")
     ap.add_argument("--graph", action="store_true", help="capture the step once into a HIP graph and replay it (same time: launch overhead is not what bounds the step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report their shard (no GPU): launcher / sharding rehearsal")
     return ap.parse_args(argv)
 
@@ -79,6 +80,21 @@ def launch_ranks(n, argv):
 # ---- the reference on the host cores -----------------------------------------------------------------------------------
 
 
+def cpu_quota():
+    """CPUs' worth of run time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def physical_cores():
     """Physical cores this process may run on: distinct (package, core) pairs among the allowed logical CPUs."""
     allowed = os.sched_getaffinity(0)
@@ -92,18 +108,49 @@ def physical_cores():
     return max(len(seen), 1), len(allowed)
 
 
+def cpu_worker(arg):
+    """`bench.py --cpu-worker t,per,width,height,channels,start` -- one host core of the reference leg: synthesise `per`
+    images of its own, wait for the common start time, then encode + free and decode + free each (sqoabench.c:527-538,
+    :490-494); prints one JSON line.  A process of its own: see cpu_baseline."""
+    import ctypes as C
+
+    from oracle import pyoracle as po
+
+    t, per, width, height, channels = (int(x) for x in arg.split(",")[:5])
+    start = float(arg.split(",")[5])
+    codec = po.best()
+    dl, nl, ddl = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
+    imgs = [po.synth(width, height, channels, "mixed", 1, t * per + k) for k in range(per)]
+    encs = [codec.encode(p, width, height, channels, 0) for p in imgs]
+    te = td = 0.0
+    while time.time() < start:  # every core enters the timed loop together
+        time.sleep(0.001)
+    t0 = time.time()
+    for p, e in zip(imgs, encs):
+        a = time.perf_counter()
+        codec.encode_raw(p.ctypes.data, C.byref(dl), C.byref(nl))
+        b = time.perf_counter()
+        codec.decode_raw(e, len(e), C.byref(ddl), 4)
+        c = time.perf_counter()
+        te += b - a
+        td += c - b
+    print(json.dumps([te, td, t0, time.time()]))
+
+
 def cpu_baseline(width, height, channels):
     """Reference codec (oracle/_ref when present, else the restatement) on the host cores, on a bounded sample of the same
     workload: (i) one thread, sqoabench protocol -- one discarded warm-up run, mean of N runs,
-    malloc + free inside the timed region (sqoabench.c:394-406, :490-494, :527-538); (ii) T threads, T = physical cores,
-    every thread encoding + decoding images of its own."""
+    malloc + free inside the timed region (sqoabench.c:394-406, :490-494, :527-538); (ii) T workers, T = physical cores,
+    every worker encoding + decoding images of its own.  Runs BEFORE this process touches the GPU (it starts processes)."""
     import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle as po
 
     codec = po.best()
     cores, logical = physical_cores()
+    quota = cpu_quota()
+    if quota is not None:  # more workers than the container's CPU share only time-slice each other
+        cores = max(1, min(cores, int(quota)))
     px_img = width * height
 
     # (i) one thread, the protocol of BENCHMARK_FN
@@ -124,43 +171,39 @@ def cpu_baseline(width, height, channels):
     single = {"encode_mpps": round(px_img * runs / t_enc / 1e6, 1), "decode_mpps": round(px_img * runs / t_dec / 1e6, 1),
               "runs": runs, "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of runs, malloc+free timed"}
 
-    # (ii) all physical cores, distinct images per thread
-    per_thread = 8  # images per thread: encode + decode of a 1 Mpixel image ~20 ms, so ~0.2 s of timed work per thread after its own synthesis
-
-    import threading
-
-    gate = threading.Barrier(cores)
-
-    def work(t):
-        dl, nl, ddl = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
-        imgs = [po.synth(width, height, channels, "mixed", 1, t * per_thread + k) for k in range(per_thread)]
-        encs = [codec.encode(p, width, height, channels, 0) for p in imgs]
-        te = td = 0.0
-        gate.wait()  # every core enters the timed loop together
-        t0 = time.perf_counter()
-        for p, e in zip(imgs, encs):
-            a = time.perf_counter()
-            codec.encode_raw(p.ctypes.data, C.byref(dl), C.byref(nl))  # malloc+free inside, sqoabench.c:527-538
-            b = time.perf_counter()
-            codec.decode_raw(e, len(e), C.byref(ddl), 4)                # sqoabench.c:490-494
-            c = time.perf_counter()
-            te += b - a
-            td += c - b
-        return te, td, t0, time.perf_counter()
-
-    with ThreadPoolExecutor(cores) as ex:
-        parts = list(ex.map(work, range(cores)))
-    busy = max(p[3] for p in parts) - min(p[2] for p in parts)  # from the common start to the last thread's last call
-    px_total = cores * per_thread * px_img
+    # (ii) all physical cores, distinct images per worker.  Workers are PROCESSES: the reference mallocs its worst-case
+    # buffer in every call (seqoia.h:492, :710), and threads of one process serialise on the address-space lock for those
+    # mmap / munmap / page-fault cycles (128 threads: 36 / 44 Mpixels/s per core against 332 / 388 alone).  Plain child
+    # processes with a common start time, each waited for with a time-out: nothing here can hang the benchmark.
+    per_thread = 8  # images per worker: encode + decode of a 1 Mpixel image ~6 ms alone, so a fraction of a second of timed work each
+    start = time.time() + 2.0 + 0.03 * cores  # interpreter start + synthesis of every worker's images fit in front of it
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t},{per_thread},{width},{height},{channels},{start}"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for t in range(cores)]
+    parts = []
+    for pr in procs:
+        try:
+            o = pr.communicate(timeout=120)[0]
+            if pr.returncode == 0:
+                parts.append(json.loads(o.decode().strip().splitlines()[-1]))
+        except Exception:  # noqa: BLE001 -- a worker that hangs or dies is dropped from the sample, never waited for
+            pr.kill()
+    if not parts:
+        return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": codec.kind, "sample": "reference workers failed", "single_thread": single}
+    late = sum(1 for p in parts if p[2] > start + 0.05)
+    cores_used = len(parts)
+    busy = max(p[3] for p in parts) - min(p[2] for p in parts)  # from the common start to the last worker's last call (time.time: one clock for all)
+    px_total = cores_used * per_thread * px_img
     return {
         "value": round(px_total / busy / 1e6, 1),
         "unit": "Mpixels/s",
-        "cores": cores,
+        "cores": cores_used,
+        "workers_started_late": late,
+        "cpu_quota": quota,
         "logical_cpus": logical,
         "kind": codec.kind,
-        "sample": f"{cores * per_thread} distinct images {width}x{height}x{channels} (class mixed, seed 1), encode+decode each, {cores} threads (one per physical core)",
-        "encode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[0] for p in parts) / cores) / 1e6, 1),
-        "decode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[1] for p in parts) / cores) / 1e6, 1),
+        "sample": f"{cores_used * per_thread} distinct images {width}x{height}x{channels} (class mixed, seed 1), encode+decode each, {cores_used} worker processes (one per physical core)",
+        "encode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[0] for p in parts) / cores_used) / 1e6, 1),
+        "decode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[1] for p in parts) / cores_used) / 1e6, 1),
         "single_thread": single,
     }
 
@@ -343,6 +386,10 @@ def run_rank(args):
             dist.destroy_process_group()
         return
 
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(args.size, args.size, 4)  # before any GPU API: it starts worker processes
+
     import torch
 
     import seqoia_amd as sq
@@ -477,8 +524,8 @@ def run_rank(args):
     out["roofline"]["decode"] = roof_dec
     if rank == 0 and world == 1 and not c5 and not args.no_secondary:
         out["config"]["secondary"] = secondary(sq, torch, dev, wl)
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(s, s, ch)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -487,6 +534,9 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:])
         return

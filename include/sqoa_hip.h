@@ -74,6 +74,17 @@ int sqoa_hip_free(int device, unsigned long long dptr);
 int sqoa_hip_memcpy_h2d(int device, unsigned long long dst, const void *src, size_t bytes);
 int sqoa_hip_memcpy_d2h(int device, void *dst, unsigned long long src, size_t bytes);
 
+/* Pinned host memory and stream-ordered copies, for callers that stage host buffers themselves (the legacy entry points
+ * of seqoia.h and the directory front-end do): a copy from pinned memory runs at PCIe speed and overlaps the caller's own
+ * work; `stream` is a handle from sqoa_hip_stream_create, or a plan's own stream (sqoa_hip_plan_stream). */
+int sqoa_hip_host_alloc(size_t bytes, void **p);
+int sqoa_hip_host_free(void *p);
+int sqoa_hip_stream_create(int device, void **stream);
+int sqoa_hip_stream_destroy(int device, void *stream);
+int sqoa_hip_stream_sync(int device, void *stream);
+int sqoa_hip_memcpy_h2d_async(int device, unsigned long long dst, const void *src, size_t bytes, void *stream);
+int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, size_t bytes, void *stream);
+
 /* Plan: uploads the job table, allocates the result table. `kind` is
  * SQOA_HIP_ENCODE or SQOA_HIP_DECODE. */
 int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_plan **out);
@@ -82,6 +93,9 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan *plan);
 /* Replace the job table of an existing plan (n <= the n it was created with):
  * same batch shape, new buffers.  Synchronises the plan's stream first. */
 int sqoa_hip_plan_update(sqoa_hip_plan *plan, const sqoa_hip_job *jobs, int n);
+
+/* The plan's own stream (what sqoa_hip_plan_launch(plan, NULL) uses), as a handle for the copy helpers above. */
+void *sqoa_hip_plan_stream(sqoa_hip_plan *plan);
 
 /* Enqueue the plan's kernels on `stream` (a hipStream_t, NULL = the plan's own
  * stream).  Asynchronous; no allocation, no host sync: graph-capturable. */

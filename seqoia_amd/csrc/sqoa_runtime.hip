@@ -106,6 +106,50 @@ int sqoa_hip_memcpy_d2h(int device, void* dst, unsigned long long src, size_t by
     return 0;
 }
 
+int sqoa_hip_host_alloc(size_t bytes, void** p) {
+    if (!p) return fail(SQOA_HIP_EINVAL, "sqoa_hip_host_alloc: null out pointer");
+    HIP_TRY(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault), SQOA_HIP_ENOMEM);
+    return 0;
+}
+
+int sqoa_hip_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+int sqoa_hip_stream_create(int device, void** stream) {
+    if (!stream) return fail(SQOA_HIP_EINVAL, "sqoa_hip_stream_create: null out pointer");
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), SQOA_HIP_ENOMEM);
+    *stream = (void*)s;
+    return 0;
+}
+
+int sqoa_hip_stream_destroy(int device, void* stream) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+int sqoa_hip_stream_sync(int device, void* stream) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream), SQOA_HIP_ELAUNCH);
+    return 0;
+}
+
+int sqoa_hip_memcpy_h2d_async(int device, unsigned long long dst, const void* src, size_t bytes, void* stream) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipMemcpyAsync((void*)(uintptr_t)dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), SQOA_HIP_EINVAL);
+    return 0;
+}
+
+int sqoa_hip_memcpy_d2h_async(int device, void* dst, unsigned long long src, size_t bytes, void* stream) {
+    HIP_TRY(hipSetDevice(device), SQOA_HIP_ENOGPU);
+    HIP_TRY(hipMemcpyAsync(dst, (const void*)(uintptr_t)src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), SQOA_HIP_EINVAL);
+    return 0;
+}
+
 // The reference's argument checks for sqoa_encode (seqoia.h:465-480).
 static bool encode_job_ok(const sqoa_hip_job& j) {
     const sqoa_desc& d = j.desc;
@@ -238,6 +282,8 @@ int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
     }
     return 0;
 }
+
+void* sqoa_hip_plan_stream(sqoa_hip_plan* p) { return p ? (void*)p->stream : nullptr; }
 
 int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");

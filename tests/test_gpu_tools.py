@@ -73,6 +73,16 @@ def test_sqoabatch_directory_roundtrip(tmp_path):
     assert subprocess.run([batch, "decode", str(enc), str(back)]).returncode == 0
     for name, (px, w, h, ch) in imgs.items():
         assert (back / f"{name}.pam").read_bytes().split(b"ENDHDR\n", 1)[1] == px.tobytes(), name
+    # several sub-batches (1 MB of input each): reader thread, GPU and writer thread overlap; same files
+    enc2, back2 = tmp_path / "enc2", tmp_path / "back2"
+    enc2.mkdir(); back2.mkdir()
+    r = subprocess.run([batch, "encode", str(src), str(enc2), "--batch-mb", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "sub-batch" in r.stdout and " in 1 sub-batch" not in r.stdout, r.stdout + r.stderr
+    for name in imgs:
+        assert (enc2 / f"{name}.sqoa").read_bytes() == (enc / f"{name}.sqoa").read_bytes(), name
+    assert subprocess.run([batch, "decode", str(enc2), str(back2), "--batch-mb", "1"]).returncode == 0
+    for name in imgs:
+        assert (back2 / f"{name}.pam").read_bytes() == (back / f"{name}.pam").read_bytes(), name
     r = subprocess.run([batch, "encode", str(src), str(qoi), "--qoi"])  # the mono image cannot be QOI: reported, others written
     assert r.returncode == 1
     for name, (px, w, h, ch) in imgs.items():
