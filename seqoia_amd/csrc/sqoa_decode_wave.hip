@@ -46,7 +46,8 @@ SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const
     for (uint32_t spin = 0; spin < DEC_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
-        if (bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+        // (the abort flag is rare news: looked at on every eighth poll)
+        if ((spin & 7u) == 7u && bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
         __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
     }
     bad = 1;
@@ -333,13 +334,19 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
         uint32_t pos_in = 0, px_in = kPxInit;
         if (c > 0) {
-            if (!chain_wait_abortable(&s_pos[(c - 1) % W], c, &s_abort, pos_in, bad)) return false;
+            // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
+            // instructions in order), so it is there when the pixel word's tag is
             if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) return false;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            pos_in = bcast_first((uint32_t)__hip_atomic_load(&s_pos[(c - 1) % W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         }
         DPHASE(4);
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-        if (!last_chunk) { post(&s_px[w], c + 1, exit_v, lane); post(&s_pos[w], c + 1, pos_out, lane); }
+        if (!last_chunk && lane == 0) {
+            __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 
         if (pos_in < N) {
             const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
