@@ -128,6 +128,14 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
     typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
     const uint32_t nb = T >> 4;
     const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (nb <= 64u) {  // run-heavy content: at most one piece per lane
+        if ((uint32_t)lane < nb) {
+#ifndef SQOA_DBG_NOSTORE
+            ((gptr128u)g)[lane] = *reinterpret_cast<const u32x4*>(stage + 16u * lane);
+#endif
+            *reinterpret_cast<uint4*>(stage + 16u * lane) = zero;
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < (ENC_STG + 1023) / 1024; ++k) {
         const uint32_t u = (uint32_t)lane + 64u * k;
@@ -493,7 +501,6 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #define PHASE(k) do { } while (0)
 #endif
     EncState st{0};
-    const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane
 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
     bool cur_raw3 = false;
@@ -578,6 +585,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         constexpr bool SW = decltype(sw_tag)::value;
         constexpr int KIND = decltype(mid_tag)::value;   // 0: general; 1 / 2: hot-loop instance (2: 4-byte pixels known)
         constexpr bool MID = KIND != 0;                   // j > 0, full sub-tiles follow, `more` is true: no edge cases in this instance
+        uint32_t lane_o = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_o));                  // (recomputed per sub-tile: two registers less live across the SQOA hot loop)
+        const unsigned long long le_mask = (2ull << lane_o) - 1ull;  // bits 0..lane
         if (MID) { __builtin_assume(j > 0); __builtin_assume(more); }
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
@@ -927,11 +937,18 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t c_in = (bcast_first(e0) & 1u) ? chain_wait(prev_run, j, st) : 0u;
                 const uint32_t nE = ~E8;
                 const uint32_t f = (uint32_t)__builtin_ctz(nE);                                   // leading repeats, 0..8 (bit 8 of ~E8 is set)
-                const uint32_t t = (uint32_t)__builtin_clz((nE << 24) | 0x00800000u);            // trailing repeats, 0..8
-                const unsigned long long below = ~allq & ((1ull << lane) - 1ull);                 // lanes below me that are not one solid run
-                const int anchor = below ? 63 - __builtin_clzll(below) : 0;
-                const uint32_t t_anchor = (uint32_t)__builtin_amdgcn_ds_bpermute(anchor << 2, (int)t);
-                const uint32_t carry = below ? 8u * ((uint32_t)lane - 1u - (uint32_t)anchor) + t_anchor : 8u * (uint32_t)lane + c_in;
+                // the sub-tile pixel index of the last pixel below my stretch that does NOT repeat: a running maximum over the lanes
+                // (one v_max_i32 per DPP step), -1 if every pixel below repeats (the run then comes from before the sub-tile)
+                const int hb = 7 - (int)__builtin_clz((nE & 0xffu) << 24);                            // my own last such pixel; clz(0) = 32: none
+                int lastne = E8 == 0xffu ? -1 : 8 * lane + hb;
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 1, 0xf, 0xf, false));
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 2, 0xf, 0xf, false));
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 4, 0xf, 0xf, false));
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 8, 0xf, 0xf, false));
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_BCAST15, 0xa, 0xf, false));
+                lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_BCAST31, 0xc, 0xf, false));
+                const int below_ne = __builtin_amdgcn_update_dpp(-1, lastne, DPP_WAVE_SHR1, 0xf, 0xf, false);   // exclusive: lanes below mine
+                const uint32_t carry = below_ne >= 0 ? (uint32_t)(8 * lane - 1 - below_ne) : 8u * (uint32_t)lane + c_in;
                 // my leading run ends in my stretch iff a pixel of mine follows it, or (all eight repeat) the pixel after my last does not
                 const bool ends = (f - 1u < 7u) || (f == 8u && (l1 >> 24) != 0u);
                 const uint32_t r = (carry + f) & 511u;
