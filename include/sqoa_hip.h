@@ -40,8 +40,17 @@ typedef struct {
     unsigned int src_size;       /* decode: stream bytes; encode: ignored */
     unsigned int dst_cap;        /* bytes available at dst */
     sqoa_desc desc;
-    unsigned int reserved;
+    unsigned int reserved;       /* 0, or for SQOA-native encode (desc.qoi_compat == 0) SQOA_HIP_JOB_* strip flags */
 } sqoa_hip_job;                  /* 40 bytes */
+
+/* Strip jobs: one image encoded by several jobs (several workgroups), each given a stretch of consecutive pixels
+ * (desc.width * desc.height = the stretch's pixel count, src = its first pixel).  A stretch must START at a pixel that
+ * differs from its predecessor (no run crosses a cut); then the jobs' streams, concatenated in pixel order behind the
+ * 15-byte header the caller writes (reference seqoia.h:497-514), are byte-identical to the one-job stream.  The legacy
+ * sqoa_encode uses this for large images; batch callers encode whole images per job and leave `reserved` 0. */
+#define SQOA_HIP_JOB_NOHEADER 1u /* no header in front of the ops */
+#define SQOA_HIP_JOB_NOEND    2u /* more pixels follow in another job: no end marker, a trailing run is flushed as a run that ends */
+#define SQOA_HIP_JOB_PREV     4u /* the first pixel's predecessor is the pixel in front of src (readable), not (0,0,0,255) */
 
 /* Per-image outcome, written by the kernels. */
 typedef struct {

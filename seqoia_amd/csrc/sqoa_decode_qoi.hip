@@ -32,6 +32,9 @@ namespace sqoa {
 #ifndef SQOA_QDEC_W_SMALL
 #define SQOA_QDEC_W_SMALL 2
 #endif
+#ifndef SQOA_QDEC_SLEEP
+#define SQOA_QDEC_SLEEP 1
+#endif
 constexpr int QK_LB = 8;                          // stream bytes per lane
 constexpr int QK_CHUNK = 64 * QK_LB;              // stream bytes per chunk
 constexpr int QK_LDS_DW = QK_CHUNK / 4 + 8;       // staged dwords: chunk + look-ahead + misalignment
@@ -56,7 +59,7 @@ SQOA_DEV bool qk_wait(unsigned long long* slot, uint32_t tag, uint32_t& val, uin
     for (uint32_t spin = 0; spin < QK_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SQOA_QDEC_SLEEP);
     }
     bad = 1;
     return false;
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         // ---- between two INDEX ops pixel values do not depend on the index: one segmented scan of the transforms per 64
         //      ops; a segment starts AT an INDEX op (whose own transform is the identity) and at the group's first op ----
+#ifndef SQOA_DBG_Q_NOSEG
         for (uint32_t gb = 0; gb < T; gb += 64) {
             const bool live = gb + (uint32_t)lane < T;
             const uint32_t m = live ? recm[gb + lane] : 0u;
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 recm[gb + lane] = (uint16_t)((m & ~6u) | (S.abs == 0xffffffffu ? 4u : S.abs ? 2u : 0u));
             }
         }
+#endif
 
         // ---- pixel position: a plain sum, handed on at once ----
         uint32_t pos_in = 0;
@@ -270,7 +275,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         // ---- the serial section: the pixel entering the chunk (and with it the index as the chunks before left it) ----
         uint32_t pxv = kPxInit;   // seqoia.h:716-719
         if (c > 0 && !qk_wait(&s_px[(c - 1) % W], c, pxv, bad)) break;
+#ifdef SQOA_DBG_Q_NOSERIAL
+        if (false) {
+#else
         if (pos_in < N) {
+#endif
             for (uint32_t gb = 0; gb < T; gb += 64) {
                 const uint32_t ng = T - gb < 64u ? T - gb : 64u;
                 const bool live = (uint32_t)lane < ng;
@@ -311,6 +320,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
         // ---- off the serial path: pixels of this chunk's ops; literal ops lane-local, runs by the whole wave ----
         uint32_t P0 = pos_in;
+#ifdef SQOA_DBG_Q_NOOUT
+        P0 = N;
+#endif
         for (uint32_t gb = 0; gb < T && P0 < N; gb += 64) {
             const bool live = gb + (uint32_t)lane < T;
             const uint32_t cnt = live ? (uint32_t)recm[gb + lane] >> 9 : 0u;

@@ -299,7 +299,7 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
 // Phase B: run bytes, byte offsets (two DPP prefix sums per four rows) and staging into LDS.
 template <bool QOI>
 SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
-                            uint32_t pa, bool has_after, uint8_t* stage, int lane, unsigned long long le_mask, uint32_t* tabw,
+                            uint32_t pa, bool has_after, bool eof, uint8_t* stage, int lane, unsigned long long le_mask, uint32_t* tabw,
                             unsigned long long* smask) {
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
     const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
@@ -344,7 +344,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                 // the whole row continues one run: at most one 0xfd (the lane where k mod 512 == 0) and, on lane 63,
                 // the flush or the trailing 0xfd -- all of it wave-uniform arithmetic
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
-                const bool end_px = s == ENC_S - 1 && !has_after;
+                const bool end_px = s == ENC_S - 1 && eof;
                 const uint32_t r0 = cr[s] & 511u, r63 = (r0 + 64u) & 511u;
                 const uint32_t fd_lane = 511u - r0;                       // < 64 iff the run crosses a multiple of 512 here
                 uint32_t n63 = 0, lo63 = 0, big63 = 0;
@@ -361,7 +361,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                 Nn += (isfd ? 1u : is63 ? n63 : 0u) << (8 * i);
             } else if (e != 0ull) {
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == bcast_lane(cur[ENC_S - 1], 63));
-                const bool end_lane = s == ENC_S - 1 && !has_after && lane == 63;  // the image's last pixel
+                const bool end_lane = s == ENC_S - 1 && eof && lane == 63;  // the image's last pixel
                 const RunOut ro = run_row<QOI>(e, cr[s], e >> 1 | nb << 63, end_lane, lane, le_mask);
                 W0 |= ro.lo << (8 * i);
                 rbig[i] = ro.big;
@@ -456,7 +456,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const int ch = (mono ? 1 : 3) + ((dch & 1) ? 0 : 1);  // input stride == header byte (seqoia.h:486, :505)
     gcptr8 src = (gcptr8)job.src;
     gptr8 dst = (gptr8)job.dst;
-    const uint32_t hdr_len = QOI ? kHeader : kHeader + 1;
+    // Strip jobs (sqoa_hip.h): a job may hold a stretch of an image's pixels only -- no header, no end marker, the pixel in front
+    // of src as the first pixel's predecessor.  SQOA-native only (the plan refuses them for QOI-compat: the colour index
+    // would have to cross the cut).
+    const uint32_t sflags = QOI ? 0u : job.reserved;
+    const bool strip_last = !(sflags & SQOA_HIP_JOB_NOEND);   // the job ends the image: end marker, and a trailing run is the single 0xfd of seqoia.h:640-642
+    const uint32_t hdr_len = (sflags & SQOA_HIP_JOB_NOHEADER) ? 0u : QOI ? kHeader : kHeader + 1;
     const uint32_t nsub = (N + ENC_SUB - 1) / ENC_SUB;
     constexpr uint32_t M = QOI ? 62u : 512u;  // seqoia.h:411-412
 
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     }
     __syncthreads();
 
-    if (w == 0 && (uint32_t)lane < hdr_len) {  // seqoia.h:497-514
+    if (w == 0 && (uint32_t)lane < hdr_len) {  // seqoia.h:497-514 (hdr_len = 0: a strip job)
         const uint32_t magic = QOI ? 0x716f6966u : 0x53716f61u;
         const uint32_t word = lane < 4 ? magic : lane < 8 ? job.desc.width : job.desc.height;
         uint8_t b = (uint8_t)(word >> (8 * (3 - (lane & 3))));
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t idx = base + s * 64 + lane;
                 px[s] = idx < N ? load_px(src, idx, ch) : 0u;
             }
-            pb = NbrPx{bcast_first(base ? load_px(src, base - 1, ch) : kPxInit), 0u, 0u, 0u};
+            pb = NbrPx{bcast_first(base ? load_px(src, base - 1, ch) : (sflags & SQOA_HIP_JOB_PREV) ? load_px(src - ch, 0, ch) : kPxInit), 0u, 0u, 0u};
             pa = NbrPx{bcast_first(base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u), 0u, 0u, 0u};
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) reinterpret_cast<uint32_t*>(pre)[s * 64 + lane] = px[s];
@@ -602,6 +607,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         const uint32_t pa = cur_pa;
         const bool has_after = MID ? true : base + ENC_SUB < N;
         const bool last_sub = MID ? false : j == nsub - 1;
+        const bool eof = !has_after && strip_last;   // the sub-tile's last pixel is the image's last
 
         // ---- pre-pass: equality masks (from the SWAR classification on the fast path), local run aggregate ----
         unsigned long long E[ENC_S];
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             // k runs over c_in+1 .. c_in+512: exactly one of them is a multiple of 512 (0xfd, seqoia.h:546-549); the
             // last pixel additionally owns the flush (seqoia.h:554-561) or the trailing 0xfd (seqoia.h:640-642)
             const uint32_t r0 = c_in & 511u;              // the 0xfd falls on pixel 511 - r0; afterwards the remainder is r0
-            const bool end_px = !has_after;
+            const bool end_px = eof;
             const bool next_eq = has_after && pa == pb;
             unsigned long long v = 0xfdull;
             uint32_t nbytes = 1, b9 = 0;
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             }
             sbase = nbytes;
         } else if (swar) {
-            sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, stage, lane, le_mask, tabw, smask);
+            sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, eof, stage, lane, le_mask, tabw, smask);
         } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t carry = pb;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 // is the pixel after lane 63 equal to lane 63's?  (next step's bit 0, or the pixel after the sub-tile)
                 const unsigned long long nb = s + 1 < ENC_S ? (E[(s + 1) % ENC_S] & 1ull) : (unsigned long long)(has_after && pa == carry);
                 const unsigned long long enext = e >> 1 | nb << 63;
-                const bool fd = iseq && (r == 0u || idx == N - 1u);
+                const bool fd = iseq && (r == 0u || (strip_last && idx == N - 1u));
                 const bool fl = iseq && !fd && !((enext >> lane) & 1ull);
                 if (fd) { lo = 0xfdu; n = 1; }
                 if (fl) {
@@ -810,8 +816,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         PHASE(6);
         if (last_sub) {  // seqoia.h:644-649
             const uint32_t end = pos + sbase;
-            if (lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
-            if (lane == 0) results[jid].len = (int)(end + 8u);
+            if (strip_last && lane < 8) dst[end + lane] = lane == 7 ? 1 : 0;
+            if (lane == 0) results[jid].len = (int)(end + (strip_last ? 8u : 0u));
 #ifdef SQOA_TRACE
             if (lane == 0) trace[1] = wall_clock64();
 #endif

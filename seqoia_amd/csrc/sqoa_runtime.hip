@@ -156,6 +156,8 @@ static bool encode_job_ok(const sqoa_hip_job& j) {
     if (!j.src || !j.dst || d.width == 0 || d.height == 0 || d.channels < 1 || d.channels > 6 || d.colorspace > 1) return false;
     if (d.height >= 400000000u / d.width) return false;
     if (d.channels < 3 && d.qoi_compat) return false;
+    if (j.reserved & ~(SQOA_HIP_JOB_NOHEADER | SQOA_HIP_JOB_NOEND | SQOA_HIP_JOB_PREV)) return false;
+    if (j.reserved && d.qoi_compat) return false;  // strip jobs: SQOA-native only (the colour index would have to cross the cut)
     return true;
 }
 

@@ -438,3 +438,55 @@ def test_l8_hot_loop_runs_of_every_length(sq, orc, ch):
         want = o.encode(imgs[k], w, h, ch, 0)
         assert s == want, (ch, k, len(s), len(want), next((i for i in range(min(len(s), len(want))) if s[i] != want[i]), None))
     plan.close()
+
+
+def test_legacy_encode_strip_jobs(sq, orc):
+    """sqoa_encode cuts a large SQOA-native image into strip jobs (several workgroups; sqoa_hip.h SQOA_HIP_JOB_*): cuts move
+    forward to a pixel that differs from its predecessor, the strips' streams are concatenated behind the header.  Byte
+    identity with the reference on images whose runs sit exactly where the nominal cuts fall, on a one-colour image (every cut
+    runs to the end), on 3-channel, mono and BGR layouts, and through the strip flags on the batch API directly."""
+    import torch
+
+    from seqoia_amd import Desc, Job
+    from seqoia_amd._lib import ENCODE
+
+    o = orc.best()
+    rng = np.random.default_rng(77)
+    w, h = 640, 480  # 307 200 pixels: 9 nominal strips
+    cases = []
+    for ch in (4, 3, 2, 1, 6):
+        stride = sq.stride_channels(ch)
+        px = rng.integers(0, 256, size=(w * h, stride), dtype=np.uint8)
+        # runs across every nominal cut position k/9 (and a few elsewhere), of lengths around the 61 / 512 boundaries
+        for k in range(1, 9):
+            a = w * h * k // 9 - int(rng.integers(0, 700))
+            px[a:a + int(rng.choice([3, 62, 63, 511, 512, 513, 1500, 40000]))] = px[a]
+        cases.append((f"runs_at_cuts_ch{ch}", px.reshape(-1), ch))
+    cases.append(("one_colour", np.full(w * h * 4, 37, dtype=np.uint8), 4))
+    cases.append(("default_pixel", np.tile(np.array([0, 0, 0, 255], dtype=np.uint8), w * h), 4))  # repeats the implicit start pixel throughout
+    grad = (np.arange(w * h, dtype=np.uint32)[:, None] >> np.array([3, 9, 14, 30], dtype=np.uint32)).astype(np.uint8)
+    cases.append(("gradient_with_long_runs", grad.reshape(-1), 4))
+    for name, px, ch in cases:
+        got = sq.encode(px, sq.Desc(w, h, ch, 0, 0))
+        assert got == o.encode(px, w, h, ch, 0), name
+        out, d = sq.decode(got, 0)
+        assert out.tobytes() == px.tobytes(), name
+    # the flags on the batch API: two strips of one image, cut by hand at a pixel that differs from its predecessor
+    name, px, ch = cases[0]
+    pxs = px.reshape(-1, 4)
+    cut = w * h // 2
+    while (pxs[cut] == pxs[cut - 1]).all():
+        cut += 1
+    t = torch.from_numpy(px).cuda()
+    out = torch.zeros((2, sq.encode_bound(sq.Desc(w * h, 1, 4, 0, 0))), dtype=torch.uint8, device="cuda")
+    jobs = [Job(t.data_ptr(), out[0].data_ptr(), 0, out.shape[1], Desc(cut, 1, 4, 0, 0), 1 | 2),
+            Job(t.data_ptr() + cut * 4, out[1].data_ptr(), 0, out.shape[1], Desc(w * h - cut, 1, 4, 0, 0), 1 | 4),
+            Job(t.data_ptr(), out[0].data_ptr(), 0, out.shape[1], Desc(cut, 1, 4, 0, 1), 1 | 2)]  # strip flags with qoi_compat: refused
+    plan = sq.Plan(ENCODE, jobs)
+    plan.launch()
+    res = plan.results()
+    assert res["status"].tolist() == [0, 0, 1]
+    want = o.encode(px, w, h, 4, 0)
+    body = bytes(out[0, : int(res["len"][0])].cpu().numpy()) + bytes(out[1, : int(res["len"][1])].cpu().numpy())
+    assert want[:15] + body == want
+    plan.close()
