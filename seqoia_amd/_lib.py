@@ -95,6 +95,13 @@ def load() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); there is no fallback path")
+        # A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64; if this library
+        # were loaded first it would pull in the system copies, and whichever copy initialises the device second finds none
+        # (sqoa_hip_device_count() == 0).  So where PyTorch exists, its runtime is loaded first and this library binds to it.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 -- no PyTorch: the system ROCm runtime is the only one
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
