@@ -42,16 +42,20 @@ constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk 
 constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
 constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 
-SQOA_DEV bool chain_wait_abortable(unsigned long long* slot, uint32_t tag, const uint32_t* abort_flag, uint32_t& val, uint32_t& bad) {
+// Wait for `slot` to carry `tag`; 0 = it does (val set), 1 = the image was handed over (abort flag), 2 = timed out.  Integer
+// result codes, not bool: a wave-uniform i1 that flows through a merge is kept as a 64-bit lane mask by the compiler
+// (s_cselect_b64 / s_and_b64 vcc, exec / s_cbranch_vccnz instead of s_cmp + s_cbranch_scc), and the scalar pipe is as busy
+// as the vector pipe in this kernel.
+SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, const uint32_t* abort_flag, uint32_t& val) {
+    uint32_t rc = 2;
     for (uint32_t spin = 0; spin < DEC_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
+        if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); rc = 0; break; }
         // (the abort flag is rare news: looked at on every eighth poll)
-        if ((spin & 7u) == 7u && bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+        if ((spin & 7u) == 7u && bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) { rc = 1; break; }
         __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
     }
-    bad = 1;
-    return false;
+    return bcast_first(rc);
 }
 
 SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
     // One chunk.  IN (compile time) = interior chunk: every byte lies inside the chunk area and a successor exists, so the
     // liveness tests and the end-of-stream handling drop out of the hot loop.  Returns false when the image is handed over.
-    auto body = [&](auto in_tag, uint32_t c) -> bool {
+    auto body = [&](auto in_tag, uint32_t c) -> uint32_t {   // 1: go on with the wave's next chunk, 0: the image is done with here
         constexpr bool IN = decltype(in_tag)::value;
         DPHASE(7);
         // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
@@ -240,7 +244,10 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(0);
         if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
-        if (c > 0 && !chain_wait_abortable(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in, bad)) return false;
+        if (c > 0) {
+            const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in);
+            if (rc) { bad |= rc >> 1; return 0u; }
+        }
         if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
         DPHASE(1);
 
@@ -316,10 +323,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             pos += adv + ((extra_m + 1023u) >> 10);
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
         }
+        iters = bcast_first(iters);  // wave-uniform by construction; said so, the slot tests below are scalar compares instead of lane masks
         const bool ref_lane = (info_or >> 20) & 1u;  // SQOA_OP_REF (what follows it in a lane is discarded with the image)
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
             if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
-            return false;
+            return 0u;
         }
 
         DPHASE(2);
@@ -336,7 +344,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         if (c > 0) {
             // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
             // instructions in order), so it is there when the pixel word's tag is
-            if (!chain_wait_abortable(&s_px[(c - 1) % W], c, &s_abort, px_in, bad)) return false;
+            const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, &s_abort, px_in);
+            if (rc) { bad |= rc >> 1; return 0u; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             pos_in = bcast_first((uint32_t)__hip_atomic_load(&s_pos[(c - 1) % W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         }
@@ -404,13 +413,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             }
             if (lane == 0) res->len = (int)(N * (uint32_t)oc);
         }
-        return true;
+        return 1u;
     };
 
     uint32_t c = w;
     if (c < nchunks) load_chunk(c, stg);
     const uint32_t nint = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
-    bool go = true;
+    uint32_t go = 1;
 #if !defined(SQOA_DEC_PRIO) || SQOA_DEC_PRIO
     // Progress-based wave priority: the SIMD arbiter is oldest-first, so of the workgroups sharing a CU the oldest runs
     // almost at solo speed and the youngest finishes alone on a nearly empty CU.  Lowering a stream's priority as it
