@@ -153,23 +153,28 @@ def cpu_baseline(width, height, channels):
         cores = max(1, min(cores, int(quota)))
     px_img = width * height
 
-    # (i) one thread, the protocol of BENCHMARK_FN
+    # (i) one thread, the protocol of BENCHMARK_FN (run before and after the multi-process leg, the faster of the two
+    # kept: the first measurement of a fresh process can fall into the container's CPU throttling)
     runs = 5
     px0 = po.synth(width, height, channels, "mixed", 1, 0)
     enc0 = codec.encode(px0, width, height, channels, 0)
-    d, n, dd = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
-    t_enc = t_dec = 0.0
-    for i in range(-1, runs):  # run -1 is the warm-up
-        a = time.perf_counter()
-        codec.decode_raw(enc0, len(enc0), C.byref(dd), 4)
-        b = time.perf_counter()
-        codec.encode_raw(px0.ctypes.data, C.byref(d), C.byref(n))
-        c = time.perf_counter()
-        if i >= 0:
-            t_dec += b - a
-            t_enc += c - b
-    single = {"encode_mpps": round(px_img * runs / t_enc / 1e6, 1), "decode_mpps": round(px_img * runs / t_dec / 1e6, 1),
-              "runs": runs, "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of runs, malloc+free timed"}
+
+    def one_thread():
+        d, n, dd = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
+        t_enc = t_dec = 0.0
+        for i in range(-1, runs):  # run -1 is the warm-up
+            a = time.perf_counter()
+            codec.decode_raw(enc0, len(enc0), C.byref(dd), 4)
+            b = time.perf_counter()
+            codec.encode_raw(px0.ctypes.data, C.byref(d), C.byref(n))
+            c = time.perf_counter()
+            if i >= 0:
+                t_dec += b - a
+                t_enc += c - b
+        return {"encode_mpps": round(px_img * runs / t_enc / 1e6, 1), "decode_mpps": round(px_img * runs / t_dec / 1e6, 1),
+                "runs": runs, "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of runs, malloc+free timed"}
+
+    single = one_thread()
 
     # (ii) all physical cores, distinct images per worker.  Workers are PROCESSES: the reference mallocs its worst-case
     # buffer in every call (seqoia.h:492, :710), and threads of one process serialise on the address-space lock for those
@@ -189,6 +194,9 @@ def cpu_baseline(width, height, channels):
             pr.kill()
     if not parts:
         return {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": codec.kind, "sample": "reference workers failed", "single_thread": single}
+    again = one_thread()
+    if 1.0 / again["encode_mpps"] + 1.0 / again["decode_mpps"] < 1.0 / single["encode_mpps"] + 1.0 / single["decode_mpps"]:
+        single = again
     late = sum(1 for p in parts if p[2] > start + 0.05)
     cores_used = len(parts)
     busy = max(p[3] for p in parts) - min(p[2] for p in parts)  # from the common start to the last worker's last call (time.time: one clock for all)

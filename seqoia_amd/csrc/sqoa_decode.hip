@@ -322,6 +322,7 @@ SQOA_DEV void qoi_front(const sqoa_hip_job& job, bool mono, QoiLds& L, int lane,
             pos += act ? len : 0u;
         }
 
+        iters = bcast_first(iters);
         if (__ballot(ref) != 0ull) {  // hand the whole image to decode_exact
             if (lane == 0) __hip_atomic_store(&L.stop, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return;

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             pos += act ? len : 0u;
         }
 
+        iters = bcast_first(iters);  // wave-uniform by construction: scalar slot tests below
         // ---- records in stream order ----
         const uint32_t oinc = wave_incl_scan(nops);
         const uint32_t T = bcast_lane(oinc, 63);
