@@ -46,14 +46,17 @@ def gather_lengths(local_idx: Sequence[int], local_len: Sequence[int], n_items: 
             out[i] = int(l)
         return out
     world = dist.get_world_size(group)
-    mine = torch.tensor([list(map(int, local_idx)), list(map(int, local_len))], dtype=torch.int64)
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([mine.shape[1]], dtype=torch.int64), group=group)
+    # RCCL ("nccl") moves device tensors only; gloo moves host tensors
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor([list(map(int, local_idx)), list(map(int, local_len))], dtype=torch.int64, device=dev).reshape(2, -1)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([mine.shape[1]], dtype=torch.int64, device=dev), group=group)
     m = int(max(s.item() for s in sizes))
-    pad = torch.full((2, m), -1, dtype=torch.int64)
+    pad = torch.full((2, m), -1, dtype=torch.int64, device=dev)
     pad[:, : mine.shape[1]] = mine
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
+    parts = [p.cpu() for p in parts]
     out = [0] * n_items
     for p in parts:
         for i, l in zip(p[0].tolist(), p[1].tolist()):
