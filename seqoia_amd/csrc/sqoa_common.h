@@ -18,6 +18,14 @@
 #define SQOA_DEC_SPIN_SLEEP 1
 #endif
 
+// Tables of the chip-wide decode passes for few large streams (sqoa_decode_wave.hip); built by the plan (sqoa_runtime.hip).
+struct sqoa_dp_tables {
+    void* d_images; int n_images;   // dp_image rows: the multi-pass images, = the first n_images of the plan's id list
+    void* d_wgs; int n_wgs;         // dp_wg rows: one per workgroup of a pass
+    void* d_tab;                    // dp_chunk rows: one per chunk
+    void* d_flags;                  // one word per image: 0 not looked at, 1 wave path, 2 left to the other kernels
+};
+
 namespace sqoa {
 
 // Device addresses arrive as integers in the job table; tell the compiler they are GLOBAL

@@ -80,15 +80,98 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 }
 
 
+// ---- chip-wide decode of few large streams: the tables of the three passes (MODE 1..3 of decode_wave_kernel) -----------------
+struct dp_image { int jid; uint32_t tab_off, nchunks, pad; };          // one multi-pass image: its job, its rows of the chunk table
+struct dp_wg { uint32_t img, chunk0; };                                 // one workgroup of a pass: image and first chunk
+struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };   // what the LDS chain carries, per chunk, in HBM
+constexpr uint32_t DP_CHUNKS_PER_WG = 16;
+
+// Entry state of every chunk: the chunks' transition functions composed in stream order, 64 chunks per step (one wave per image).
+__global__ __launch_bounds__(64) void dp_scan_state(const dp_image* __restrict__ images, dp_chunk* __restrict__ tabs, const uint32_t* __restrict__ flags) {
+    const int lane = lane_id();
+    const dp_image im = images[blockIdx.x];
+    if (flags[blockIdx.x] != 1u) return;
+    dp_chunk* tab = tabs + im.tab_off;
+    uint32_t st = ST_N;   // stream start (seqoia.h:773-775)
+    for (uint32_t base = 0; base < im.nchunks; base += 64) {
+        const uint32_t c = base + lane;
+        Fn F{ID_LO, ID_HI};
+        if (c < im.nchunks) { F.lo = tab[c].g_lo; F.hi = tab[c].g_hi; }
+        const Fn Fi = wave_compose_scan(F);
+        const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
+        if (c < im.nchunks) tab[c].st_in = apply(Fx, st);
+        st = apply(Fn{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)}, st);
+    }
+}
+
+template <int CTRL, int ROWMASK>
+SQOA_DEV uint32_t dp_sat_step(uint32_t v, uint32_t cap) {
+    const uint32_t s = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+    return s > cap ? cap : s;
+}
+
+// forward decl: the transform scan lives below
+SQOA_DEV Xf wave_xf_scan(Xf T);
+
+// Pixel position and entering pixel of every chunk: prefix sum of the pixel counts (saturating at N: counts of crafted streams
+// overflow 32 bits otherwise) and prefix composition of the transforms.
+__global__ __launch_bounds__(64) void dp_scan_pixels(const sqoa_hip_job* __restrict__ jobs, const dp_image* __restrict__ images, dp_chunk* __restrict__ tabs,
+                                                     const uint32_t* __restrict__ flags) {
+    const int lane = lane_id();
+    const dp_image im = images[blockIdx.x];
+    if (flags[blockIdx.x] != 1u) return;
+    gcptr8 src = (gcptr8)jobs[im.jid].src;
+    const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+    const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+    const uint32_t N = hw * hh;
+    dp_chunk* tab = tabs + im.tab_off;
+    uint32_t pos = 0, px = kPxInit;
+    for (uint32_t base = 0; base < im.nchunks; base += 64) {
+        const uint32_t c = base + lane;
+        const bool live = c < im.nchunks;
+        const uint32_t cnt = live ? tab[c].ctot : 0u;
+        Xf T{live ? tab[c].tv : 0u, live ? tab[c].tabs : 0u};
+        uint32_t v = cnt;
+        v = dp_sat_step<DPP_ROW_SHR + 1, 0xf>(v, N);
+        v = dp_sat_step<DPP_ROW_SHR + 2, 0xf>(v, N);
+        v = dp_sat_step<DPP_ROW_SHR + 4, 0xf>(v, N);
+        v = dp_sat_step<DPP_ROW_SHR + 8, 0xf>(v, N);
+        v = dp_sat_step<DPP_ROW_BCAST15, 0xa>(v, N);
+        v = dp_sat_step<DPP_ROW_BCAST31, 0xc>(v, N);
+        const uint32_t before = shift_up1(v, 0u);                      // pixels of the chunks below mine in this group (saturated)
+        const Xf Ti = wave_xf_scan(T);
+        const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
+        if (live) {
+            const uint32_t p = pos + before;
+            tab[c].pos_in = p > N ? N : p;
+            tab[c].px_in = xf_apply(Tx, px);
+        }
+        const uint32_t tot = bcast_lane(v, 63);
+        pos = pos + tot > N ? N : pos + tot;
+        px = xf_apply(Xf{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)}, px);
+    }
+}
+
 // 64 VGPRs = 8 waves per SIMD = four 8-wave streams per CU (see sqoa_encode.hip)
 #ifndef SQOA_DEC_WPE
 #define SQOA_DEC_WPE 8
 #endif
 #define SQOA_DEC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SQOA_DEC_WPE, SQOA_DEC_WPE)))
-template <int W>
+// MODE 0: one workgroup per image, the chunks chained through LDS (the batch shape: as many images as the chip holds workgroups).
+// MODE 1..3: the three passes that decode FEW LARGE streams with the whole chip instead of one compute unit per stream (a
+// lone 1 Mpixel stream takes 2.2 ms chained: one CU's instruction issue).  A workgroup takes a range of chunks of one image;
+// what the chain carries travels through a per-chunk table in HBM (dp_chunk) between launches:
+//   pass 1: parse only -> the chunk's transition function; dp_scan_state then gives every chunk its entry state;
+//   pass 2: parse + walk + scans -> the chunk's pixel count and composite transform; dp_scan_pixels gives every chunk the
+//           pixel position and the pixel it starts from;
+//   pass 3: parse + walk + scans again, and the stores.
+// Twice the instructions of MODE 0, spread over every CU.
+template <int W, int MODE>
 __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                              const int* __restrict__ job_ids,
-                                                             sqoa_hip_result* __restrict__ results) {
+                                                             sqoa_hip_result* __restrict__ results,
+                                                             const dp_image* __restrict__ dp_images, const dp_wg* __restrict__ dp_wgs,
+                                                             dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
@@ -106,14 +189,24 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
-    const int jid = job_ids[blockIdx.x];
+    uint32_t img = 0, chunk_first = 0, tab_off = 0;   // MODE > 0: the image and the chunk range of this workgroup
+    int jid;
+    if constexpr (MODE == 0) jid = job_ids[blockIdx.x];
+    else {
+        img = dp_wgs[blockIdx.x].img;
+        chunk_first = dp_wgs[blockIdx.x].chunk0;
+        jid = dp_images[img].jid;
+        tab_off = dp_images[img].tab_off;
+    }
     const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
     gcptr8 src = (gcptr8)job.src;
     gptr8 out = (gptr8)job.dst;
     const uint32_t size = job.src_size;
+    dp_chunk* tab = MODE ? dp_tab + tab_off : nullptr;
 
-    if (threadIdx.x == 0) {
+    if (MODE >= 2 && threadIdx.x == 0) { s_abort = 0; s_path = dp_flags[img]; }   // what pass 1 (or pass 2: SQOA_OP_REF) decided
+    if ((MODE == 0 || (MODE == 1 && chunk_first == 0)) && threadIdx.x == 0) {
         s_abort = 0;
         // header (seqoia.h:672-688): written to the result exactly as sqoa_decode fills *desc
         const uint32_t magic = (uint32_t)src[0] << 24 | (uint32_t)src[1] << 16 | (uint32_t)src[2] << 8 | src[3];
@@ -135,7 +228,9 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }
         }
         s_path = path;
+        if (MODE == 1) dp_flags[img] = path;
     }
+    if (MODE == 1 && chunk_first != 0 && threadIdx.x == 0) { s_abort = 0; s_path = 1; }  // (parsing bytes is harmless whatever the header says)
     if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
     for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // transition function of a live byte (see header comment)
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
@@ -174,6 +269,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const uint32_t chunks_len = size_a - 8;     // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
+    // the chunks this workgroup takes: all of them, or (MODE > 0) DP_CHUNKS_PER_WG from chunk_first on
+    const uint32_t chunk_end = MODE == 0 ? nchunks : (chunk_first + DP_CHUNKS_PER_WG < nchunks ? chunk_first + DP_CHUNKS_PER_WG : nchunks);
     uint32_t bad = 0;
 
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
@@ -214,7 +311,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #pragma unroll
         for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
         if (lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) lds[lane + 64 * (DEC_NLD - 1)] = stg[DEC_NLD - 1];
-        const bool more = c + W < nchunks;
+        const bool more = c + W < chunk_end;
         if (more) load_chunk(c + W, stg);
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
         const uint8_t* cb = reinterpret_cast<const uint8_t*>(lds) + (gs & 3u);
@@ -242,13 +339,20 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const bool g_const = G.lo == g0 * 0x01010101u && (G.hi & 0xffffu) == g0 * 0x0101u;
         unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
         DPHASE(0);
-        if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
-        if (c > 0) {
-            const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in);
-            if (rc) { bad |= rc >> 1; return 0u; }
+        if constexpr (MODE == 0) {
+            if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
+            if (c > 0) {
+                const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in);
+                if (rc) { bad |= rc >> 1; return 0u; }
+            }
+            if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
+        } else if constexpr (MODE == 1) {
+            if (lane == 0) { tab[c].g_lo = G.lo; tab[c].g_hi = G.hi; }
+            return 1u;
+        } else {
+            if (c > 0) st_in = bcast_first(tab[c].st_in);
         }
-        if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
         DPHASE(1);
 
         // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
@@ -326,7 +430,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         iters = bcast_first(iters);  // wave-uniform by construction; said so, the slot tests below are scalar compares instead of lane masks
         const bool ref_lane = (info_or >> 20) & 1u;  // SQOA_OP_REF (what follows it in a lane is discarded with the image)
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
-            if (lane == 0) { __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); }
+            if (lane == 0) {
+                __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
+                if (MODE) atomicMax(&dp_flags[img], 2u);   // pass 3 leaves the image to the exact decoder
+            }
             return 0u;
         }
 
@@ -340,8 +448,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
         DPHASE(3);
         // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
+        if constexpr (MODE == 2) {
+            if (lane == 0) { tab[c].ctot = ctot > N ? N : ctot; tab[c].tv = Tg.v; tab[c].tabs = Tg.abs; }
+            return 1u;
+        }
         uint32_t pos_in = 0, px_in = kPxInit;
-        if (c > 0) {
+        if (MODE == 3 && c > 0) { pos_in = bcast_first(tab[c].pos_in); px_in = bcast_first(tab[c].px_in); }
+        if (MODE == 0 && c > 0) {
             // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
             // instructions in order), so it is there when the pixel word's tag is
             const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, &s_abort, px_in);
@@ -352,7 +465,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(4);
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-        if (!last_chunk && lane == 0) {
+        if (MODE == 0 && !last_chunk && lane == 0) {
             __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -416,10 +529,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         return 1u;
     };
 
-    uint32_t c = w;
-    if (c < nchunks) load_chunk(c, stg);
-    const uint32_t nint = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
+    uint32_t c = chunk_first + w;
+    if (c < chunk_end) load_chunk(c, stg);
+    const uint32_t nint_all = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
+    const uint32_t nint = nint_all < chunk_end ? nint_all : chunk_end;
     uint32_t go = 1;
+    if constexpr (MODE == 0) {
 #if !defined(SQOA_DEC_PRIO) || SQOA_DEC_PRIO
     // Progress-based wave priority: the SIMD arbiter is oldest-first, so of the workgroups sharing a CU the oldest runs
     // almost at solo speed and the youngest finishes alone on a nearly empty CU.  Lowering a stream's priority as it
@@ -440,7 +555,10 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #else
     for (; go && c < nint; c += W) go = body(std::true_type{}, c);
 #endif
-    for (; go && c < nchunks; c += W) go = body(std::false_type{}, c);
+    } else {
+        for (; go && c < nint; c += W) go = body(std::true_type{}, c);
+    }
+    for (; go && c < chunk_end; c += W) go = body(std::false_type{}, c);
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 #ifdef SQOA_TRACE
     if (threadIdx.x == 0) { unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull); for (int k = 0; k < 8; ++k) tr[k] = ph[k]; }
@@ -456,6 +574,37 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 #define SQOA_DEC_W 8
 #endif
     constexpr int W = SQOA_DEC_W;
-    hipLaunchKernelGGL((sqoa::decode_wave_kernel<W>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError();
+}
+
+// Few large streams: three passes over all their chunks with the whole chip (see decode_wave_kernel), two one-wave-per-image scans
+// in between.  `d_images` / `d_wgs` / `d_tab` / `d_flags`: the tables the plan built (sqoa_runtime.hip).
+extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, hipStream_t stream) {
+    if (n_images <= 0 || n_wgs <= 0) return hipSuccess;
+    using namespace sqoa;
+    constexpr int W = 8;
+    const dp_image* im = (const dp_image*)d_images;
+    const dp_wg* wg = (const dp_wg*)d_wgs;
+    dp_chunk* tab = (dp_chunk*)d_tab;
+    uint32_t* fl = (uint32_t*)d_flags;
+    hipError_t e = hipMemsetAsync(fl, 0, sizeof(uint32_t) * (size_t)n_images, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
+    hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(64), 0, stream, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
+    hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(64), 0, stream, d_jobs, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
+    return hipGetLastError();
+}
+
+// What the plan needs to lay the pass tables out (sqoa_runtime.hip): rows of the chunk table and chunks per workgroup for a stream of
+// `src_size` bytes (the chunk area is what lies between header + start byte and the 8 end bytes, as in decode_wave_kernel).
+extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes) {
+    const uint32_t area = src_size > 23u ? src_size - 23u : 0u;
+    const uint32_t nc = area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
+    *nchunks = nc;
+    *chunks_per_wg = sqoa::DP_CHUNKS_PER_WG;
+    *chunk_row_bytes = sizeof(sqoa::dp_chunk);
 }

@@ -7,6 +7,7 @@
 // reference's own (seqoia.h:465-480) so a job the reference would refuse is
 // reported as SQOA_HIP_ST_BADARG instead of being launched.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -16,8 +17,20 @@
 
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes);
+
+// A stream decoded by one workgroup runs at one compute unit's instruction issue (about 1.1 MB of stream per ms) however empty
+// the chip is; the three-pass decode costs about twice the instructions but spreads them over every CU (about 1300 MB / ms for
+// the chip).  A stream goes multi-pass when it alone would outlast the rest of the batch: SQOA_DP_RATIO x its bytes > the bytes
+// of itself and everything smaller.  (Measured on 1024x1024 images: 256 of them take 2.2 ms either way, 64 take 0.64 against 2.15 ms, one 0.11 against 1.99 ms.)
+#ifndef SQOA_DP_RATIO
+#define SQOA_DP_RATIO 192ull
+#endif
+#ifndef SQOA_DP_MIN_BYTES
+#define SQOA_DP_MIN_BYTES (16u << 10)
+#endif
 
 static thread_local char g_err[256] = "";
 
@@ -43,6 +56,8 @@ struct sqoa_hip_plan {
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
+    size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;       // recorded behind the kernels of the most recent launch, on whatever stream it used
@@ -189,10 +204,32 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     auto heavier = [&](int a, int b) { return weight(a) > weight(b); };
     std::stable_sort(ids_a.begin(), ids_a.end(), heavier);
     std::stable_sort(ids_b.begin(), ids_b.end(), heavier);
+    struct dp_image_row { int jid; uint32_t tab_off, nchunks, pad; };   // = sqoa::dp_image / dp_wg (sqoa_decode_wave.hip)
+    struct dp_wg_row { uint32_t img, chunk0; };
+    std::vector<dp_image_row> dp_images;
+    std::vector<dp_wg_row> dp_wgs;
+    size_t dp_rows = 0, dp_row_bytes = 32;
     if (p->kind == SQOA_HIP_DECODE) {
         unsigned long long bytes = 0;
         for (int i : ids_a) bytes += jobs[i].src_size;
         p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
+        // ids_a is sorted by size: the multi-pass streams are a prefix of it
+        // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
+        const char* knob = getenv("SQOA_HIP_MULTIPASS");
+        const int force = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
+        unsigned long long rest = bytes;
+        for (int i : ids_a) {
+            const unsigned long long b = jobs[i].src_size;
+            if (force < 0 || (force == 0 && (b < SQOA_DP_MIN_BYTES || b * SQOA_DP_RATIO <= rest))) break;
+            uint32_t nc, per;
+            sqoa_dp_layout(jobs[i].src_size, &nc, &per, &dp_row_bytes);
+            if (dp_rows + nc > 0xffffffffull) break;
+            const uint32_t img = (uint32_t)dp_images.size();
+            dp_images.push_back({i, (uint32_t)dp_rows, nc, 0u});
+            for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});
+            dp_rows += nc;
+            rest -= b;
+        }
     }
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
@@ -204,6 +241,29 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         (e = hipMemcpy(p->d_init, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
         (!ids_a.empty() && (e = hipMemcpy(p->d_ids, ids_a.data(), sizeof(int) * ids_a.size(), hipMemcpyHostToDevice)) != hipSuccess))
         return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
+    p->dp.n_images = (int)dp_images.size();
+    p->dp.n_wgs = (int)dp_wgs.size();
+    if (!dp_images.empty()) {
+        auto grow = [&](void** d, size_t* cap, size_t rows, size_t row_bytes) -> hipError_t {
+            if (rows <= *cap) return hipSuccess;
+            if (*d) { hipError_t e2 = hipFree(*d); *d = nullptr; *cap = 0; if (e2 != hipSuccess) return e2; }
+            hipError_t e2 = hipMalloc(d, rows * row_bytes);
+            if (e2 == hipSuccess) *cap = rows;
+            return e2;
+        };
+        if ((e = grow(&p->dp.d_flags, &p->dp_flags_cap, dp_images.size(), sizeof(uint32_t))) != hipSuccess ||
+            (e = grow(&p->dp.d_images, &p->dp_images_cap, dp_images.size(), sizeof(dp_image_row))) != hipSuccess ||
+            (e = grow(&p->dp.d_wgs, &p->dp_wgs_cap, dp_wgs.size(), sizeof(dp_wg_row))) != hipSuccess ||
+            (e = grow(&p->dp.d_tab, &p->dp_tab_cap, dp_rows, dp_row_bytes)) != hipSuccess) {
+            p->dp.n_images = p->dp.n_wgs = 0;
+            return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan: tables of the multi-pass decode", e);
+        }
+        if ((e = hipMemcpy(p->dp.d_images, dp_images.data(), sizeof(dp_image_row) * dp_images.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->dp.d_wgs, dp_wgs.data(), sizeof(dp_wg_row) * dp_wgs.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+            p->dp.n_images = p->dp.n_wgs = 0;
+            return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the multi-pass decode, upload", e);
+        }
+    }
     return 0;
 }
 
@@ -250,6 +310,10 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->d_results) hipFree(p->d_results);
     if (p->d_init) hipFree(p->d_init);
     if (p->d_ids) hipFree(p->d_ids);
+    if (p->dp.d_images) hipFree(p->dp.d_images);
+    if (p->dp.d_wgs) hipFree(p->dp.d_wgs);
+    if (p->dp.d_tab) hipFree(p->dp.d_tab);
+    if (p->dp.d_flags) hipFree(p->dp.d_flags);
     if (p->ev0) hipEventDestroy(p->ev0);
     if (p->ev1) hipEventDestroy(p->ev1);
     if (p->stream) hipStreamDestroy(p->stream);
@@ -264,7 +328,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids, p->n_sqoa, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }

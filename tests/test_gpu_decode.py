@@ -23,6 +23,14 @@ def orc():
     return po
 
 
+@pytest.fixture(params=["0", "1"], ids=["chained", "threepass"])
+def route(request, monkeypatch):
+    """Both routes of the SQOA wave decoder (the plan reads SQOA_HIP_MULTIPASS when it is filled): one workgroup per stream
+    with the chunks chained through LDS, and the three chip-wide passes the plan picks by itself for few large streams."""
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", request.param)
+    return request.param
+
+
 def test_legacy_decode_kats(sq, kat_decode):
     """sqoa_decode on every crafted stream captured from the compiled reference: REF ops, ALPHA
     suffixes, leading ALPHA as run, mono / 128-entry index, exhausted streams, header rejects."""
@@ -88,7 +96,7 @@ def test_batch_roundtrip_and_oracle(sq, orc, mode, cls, w, h, ch, n):
     enc.close()
 
 
-def test_batch_decode_mutants_match_oracle(sq, orc):
+def test_batch_decode_mutants_match_oracle(sq, orc, route):
     """Differential fuzz on the batch path (successor of sqoafuzz.c:20-32): mutated encoder output must
     decode exactly as the reference decodes it, or be refused exactly when the reference refuses."""
     import torch
@@ -123,7 +131,7 @@ def test_batch_decode_mutants_match_oracle(sq, orc):
     dec.close()
 
 
-def test_wave_decoder_chunk_boundaries(sq, orc):
+def test_wave_decoder_chunk_boundaries(sq, orc, route):
     """Crafted multi-chunk SQOA streams (the wave decoder cuts the stream every 512 bytes, 8 bytes per lane):
     every alignment of 1/2/3/4/5/6-byte ops against lane and chunk boundaries, ALPHA suffix as first byte of a
     lane / chunk, op bytes that look like op starts, REF op deep in the stream (hand-over to the serial kernel
@@ -177,6 +185,17 @@ def test_wave_decoder_chunk_boundaries(sq, orc):
     streams.append(hdr(96, 64) + b"\x6a" + body(300, full) + END)                          # leading ALPHA byte is a run
     streams.append(hdr(300, 300) + body(40, ["bigrun", "run"]) + END)                      # runs overshoot the image
     streams.append(hdr(96, 64, 3) + body(700, ["luma", "rgb", "run", "luma_a"]) + END)     # 3-channel file, 4-channel output
+    # long streams: several workgroups of 16 chunks each on the three-pass route (entry state, position and pixel of a chunk
+    # come from the table the scan kernels fill, not from the neighbour wave)
+    lit = ["luma", "luma_a", "rgb", "rgb_a", "rgba", "rgba_a", "alpha_alpha"]
+    for shift in range(4):
+        streams.append(hdr(200, 160) + b"\xc0" * shift + body(9000, lit + ["run"]) + END)
+    streams.append(hdr(200, 160) + body(6000, lit) + b"\x45" + body(3000, lit) + END)       # REF op in the third workgroup
+    streams.append((hdr(200, 160) + body(9000, lit) + END)[:-13])                          # exhausted inside the last ops
+    streams.append(hdr(200, 160) + body(4000, lit) + END)                                  # stream ends early: the last pixel repeats
+    streams.append(hdr(200, 160) + body(3000, lit) + body(6000, ["bigrun", "run", "luma"]) + END)  # runs overshoot from the 2nd workgroup on
+    streams.append(hdr(200, 160, 3) + body(9000, ["luma", "rgb", "run", "luma_a"]) + END)
+    streams.append(hdr(96, 64) + body(9000, lit + ["run"]) + END)                          # more ops than pixels: the later workgroups store nothing
     wants = [o.decode(s, 4) for s in streams]
     slot = max(len(s) for s in streams) + 32
     buf = np.zeros((len(streams), slot), dtype=np.uint8)
@@ -303,7 +322,7 @@ def test_results_wait_for_a_launch_on_the_callers_stream(sq, orc):
     enc.close()
 
 
-def test_decode_to_unaligned_rgba_destination_and_shape_check(sq, orc):
+def test_decode_to_unaligned_rgba_destination_and_shape_check(sq, orc, route):
     """A 4-channel destination that is not dword-aligned takes byte stores (every decoder); a stream whose header does
     not have the shape the job states is refused (SQOA_HIP_ST_BADARG) instead of being written with scrambled rows."""
     import torch
@@ -377,7 +396,7 @@ def test_plans_replay_from_a_hip_graph(sq, orc):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_large_single_image(sq, orc, mode):
+def test_large_single_image(sq, orc, mode, route):
     """One screenshot-sized image (3840x2160, the largest class of SURVEY.md Appendix C's suite table): 16 200
     sub-tiles through one workgroup's chains, output positions beyond 2^24, both wire formats, encode and decode."""
     import torch
@@ -399,7 +418,7 @@ def test_large_single_image(sq, orc, mode):
     enc.close()
 
 
-def test_batch_decode_random_bodies_match_oracle(sq, orc):
+def test_batch_decode_random_bodies_match_oracle(sq, orc, route):
     """Differential fuzz with NO structure: random bytes behind a valid header (successor of sqoafuzz.c:20-32 on the
     batch path).  SQOA bodies hit REF / ALPHA / run-as-op paths at random; QOI bodies hit INDEX on an empty table;
     mono headers go to the 128-entry index.  The GPU must agree with the reference on every stream, including
@@ -480,7 +499,7 @@ def test_qoi_long_random_streams_match_oracle(sq, orc):
         dec.close()
 
 
-def test_decode_from_packed_blob_at_any_byte_address(sq, orc):
+def test_decode_from_packed_blob_at_any_byte_address(sq, orc, route):
     """Streams compacted by sqoa_hip_pack sit back to back, i.e. at arbitrary byte addresses; the wave-parallel decoders
     (SQOA and QOI-compat) take them where they are: exact pixels for every alignment of the stream start."""
     import torch
