@@ -518,7 +518,7 @@ def run_rank(args):
         "kernel_ms": round(enc_ms, 4), "traffic": enc_traffic,
     }
     roof_dec = {
-        "kernel": "sqoa::decode_wave_kernel<8>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "kernel": "sqoa::decode_wave_kernel<8,0>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
         "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
         "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
         "kernel_ms": round(dec_ms, 4), "traffic": dec_traffic,

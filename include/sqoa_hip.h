@@ -95,7 +95,10 @@ int sqoa_hip_memcpy_h2d_async(int device, unsigned long long dst, const void *sr
 int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, size_t bytes, void *stream);
 
 /* Plan: uploads the job table, allocates the result table. `kind` is
- * SQOA_HIP_ENCODE or SQOA_HIP_DECODE. */
+ * SQOA_HIP_ENCODE or SQOA_HIP_DECODE.
+ * A decode plan chooses per stream between one workgroup per stream (a full batch) and three chip-wide passes (few large
+ * streams: one workgroup is one compute unit's speed); SQOA_HIP_MULTIPASS=0 / =1 in the environment when the plan is
+ * created or updated forces the one or the other for every stream (tests, measurements; the decoded bytes are the same). */
 int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_plan **out);
 void sqoa_hip_plan_destroy(sqoa_hip_plan *plan);
 

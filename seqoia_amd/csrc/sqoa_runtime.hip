@@ -21,12 +21,17 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes);
 
-// A stream decoded by one workgroup runs at one compute unit's instruction issue (about 1.1 MB of stream per ms) however empty
-// the chip is; the three-pass decode costs about twice the instructions but spreads them over every CU (about 1300 MB / ms for
-// the chip).  A stream goes multi-pass when it alone would outlast the rest of the batch: SQOA_DP_RATIO x its bytes > the bytes
-// of itself and everything smaller.  (Measured on 1024x1024 images: 256 of them take 2.2 ms either way, 64 take 0.64 against 2.15 ms, one 0.11 against 1.99 ms.)
-#ifndef SQOA_DP_RATIO
-#define SQOA_DP_RATIO 192ull
+// A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
+// empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
+// 660 MB / ms for the chip; tools/time_few.py: 1024x1024 images, one 0.11 against 1.99 ms, 64: 0.64 against 2.15 ms, 256: 2.2
+// ms either way, 1024: 8.45 against 3.73 ms).  The plan sorts the streams by size and sends the k largest through the passes,
+// k minimising      SQOA_DP_COST * bytes(first k) + max(SQOA_DP_SOLO * bytes(stream k), bytes(rest))        [time x R]
+// i.e. the passes, then the one-workgroup-per-stream kernel bounded by its largest stream or by the chip.
+#ifndef SQOA_DP_COST
+#define SQOA_DP_COST 2.27
+#endif
+#ifndef SQOA_DP_SOLO
+#define SQOA_DP_SOLO (550.0 * 1.25)   // R / r, x 1.25: a stream that shares its CU with other streams is slower than alone
 #endif
 #ifndef SQOA_DP_MIN_BYTES
 #define SQOA_DP_MIN_BYTES (16u << 10)
@@ -217,10 +222,21 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
         const int force = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
-        unsigned long long rest = bytes;
-        for (int i : ids_a) {
-            const unsigned long long b = jobs[i].src_size;
-            if (force < 0 || (force == 0 && (b < SQOA_DP_MIN_BYTES || b * SQOA_DP_RATIO <= rest))) break;
+        size_t k_best = 0;
+        if (force > 0) k_best = ids_a.size();
+        else if (force == 0) {
+            double best = 0, head = 0;
+            for (size_t k = 0; k <= ids_a.size(); ++k) {
+                const double bk = k < ids_a.size() ? (double)jobs[ids_a[k]].src_size : 0.0;
+                const double rest = (double)bytes - head;
+                const double cost = SQOA_DP_COST * head + (SQOA_DP_SOLO * bk > rest ? SQOA_DP_SOLO * bk : rest);
+                if (k == 0 || cost < best) { best = cost; k_best = k; }
+                if (k == ids_a.size() || jobs[ids_a[k]].src_size < SQOA_DP_MIN_BYTES) break;
+                head += bk;
+            }
+        }
+        for (size_t k = 0; k < k_best; ++k) {
+            const int i = ids_a[k];
             uint32_t nc, per;
             sqoa_dp_layout(jobs[i].src_size, &nc, &per, &dp_row_bytes);
             if (dp_rows + nc > 0xffffffffull) break;
@@ -228,7 +244,6 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             dp_images.push_back({i, (uint32_t)dp_rows, nc, 0u});
             for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});
             dp_rows += nc;
-            rest -= b;
         }
     }
     p->n = n;
