@@ -99,6 +99,12 @@ int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, siz
  * A decode plan chooses per stream between one workgroup per stream (a full batch) and three chip-wide passes (few large
  * streams: one workgroup is one compute unit's speed); SQOA_HIP_MULTIPASS=0 / =1 in the environment when the plan is
  * created or updated forces the one or the other for every stream (tests, measurements; the decoded bytes are the same). */
+/* The choice a decode plan makes, as a pure host function (no device needed): order[0 .. *n_multipass) = the streams that take
+ * the three passes, largest first; order[*n_multipass .. n) = the dispatch order of the streams that get a workgroup each
+ * (largest first, every second run of `cus` reversed so that the compute units' loads even out).  `src_sizes[i]` = stream
+ * bytes, `cus` = compute units of the device (256), `mode` 0 = cost model, -1 = never multi-pass, 1 = always. */
+int sqoa_hip_decode_route(const unsigned int *src_sizes, int n, int cus, int mode, int *order, int *n_multipass);
+
 int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_plan **out);
 void sqoa_hip_plan_destroy(sqoa_hip_plan *plan);
 

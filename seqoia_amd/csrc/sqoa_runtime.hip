@@ -181,6 +181,45 @@ static bool encode_job_ok(const sqoa_hip_job& j) {
     return true;
 }
 
+// Every second run of `cus` ids reversed, from `first` on.  The dispatcher hands workgroups to the compute units round-robin,
+// so of a batch that fits the chip at once (four streams per CU) CU k gets ranks k, C + k, 2C + k, 3C + k of a sorted list:
+// CU 0 would get the largest stream of every quarter.  Boustrophedon order evens the CUs' loads out (headline decode: max / mean
+// CU load 1.026 -> 1.001, 3.74 -> 3.70 ms).
+static void snake(std::vector<int>& v, size_t first, int cus) {
+    for (size_t a = first + cus; a < v.size(); a += 2 * (size_t)cus) std::reverse(v.begin() + a, v.begin() + std::min(v.size(), a + cus));
+}
+
+// Dispatch order of a decode plan's streams and the route each takes: pure host arithmetic, no device needed.
+// order[0 .. *n_multipass) = the streams decoded in three chip-wide passes (largest first), order[*n_multipass .. n) = the ones
+// that get a workgroup each.  `mode`: 0 = the cost model above, -1 = no stream multi-pass, 1 = every stream.
+int sqoa_hip_decode_route(const unsigned int* src_sizes, int n, int cus, int mode, int* order, int* n_multipass) {
+    if (!src_sizes || !order || !n_multipass || n < 0 || cus <= 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_decode_route: bad arguments");
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; ++i) ids[i] = i;
+    // one workgroup per stream, dispatched in id order: the largest first, so that a batch of mixed sizes (BASELINE.json
+    // configs[4]) does not end with one screenshot-sized stream running alone
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return src_sizes[a] > src_sizes[b]; });
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) bytes += src_sizes[i];
+    size_t k_best = 0;
+    if (mode > 0) k_best = (size_t)n;
+    else if (mode == 0) {
+        double best = 0, head = 0;
+        for (size_t k = 0; k <= (size_t)n; ++k) {
+            const double bk = k < (size_t)n ? (double)src_sizes[ids[k]] : 0.0;
+            const double rest = bytes - head;
+            const double cost = SQOA_DP_COST * head + (SQOA_DP_SOLO * bk > rest ? SQOA_DP_SOLO * bk : rest);
+            if (k == 0 || cost < best) { best = cost; k_best = k; }
+            if (k == (size_t)n || src_sizes[ids[k]] < SQOA_DP_MIN_BYTES) break;
+            head += bk;
+        }
+    }
+    snake(ids, k_best, cus);
+    memcpy(order, ids.data(), sizeof(int) * (size_t)n);
+    *n_multipass = (int)k_best;
+    return 0;
+}
+
 // Classify jobs, fill the pre-launch result rows and the per-variant id lists, upload all three.
 static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     std::vector<sqoa_hip_result> init(n ? n : 1);
@@ -200,46 +239,42 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             ids_a.push_back(i);
         }
     }
-    // One workgroup per image and workgroups are dispatched in id order: the largest images first, so that a batch of mixed
-    // sizes (BASELINE.json configs[4]) does not end with one screenshot-sized image running alone (longest-processing-time-first
-    // inside the device as well as across the ranks)
-    auto weight = [&](int i) -> unsigned long long {
-        return p->kind == SQOA_HIP_ENCODE ? (unsigned long long)jobs[i].desc.width * jobs[i].desc.height : jobs[i].src_size;
-    };
-    auto heavier = [&](int a, int b) { return weight(a) > weight(b); };
-    std::stable_sort(ids_a.begin(), ids_a.end(), heavier);
-    std::stable_sort(ids_b.begin(), ids_b.end(), heavier);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
     struct dp_image_row { int jid; uint32_t tab_off, nchunks, pad; };   // = sqoa::dp_image / dp_wg (sqoa_decode_wave.hip)
     struct dp_wg_row { uint32_t img, chunk0; };
     std::vector<dp_image_row> dp_images;
     std::vector<dp_wg_row> dp_wgs;
     size_t dp_rows = 0, dp_row_bytes = 32;
-    if (p->kind == SQOA_HIP_DECODE) {
+    if (p->kind == SQOA_HIP_ENCODE) {
+        // largest image first (see sqoa_hip_decode_route), then boustrophedon
+        auto heavier = [&](int a, int b) {
+            return (unsigned long long)jobs[a].desc.width * jobs[a].desc.height > (unsigned long long)jobs[b].desc.width * jobs[b].desc.height;
+        };
+        std::stable_sort(ids_a.begin(), ids_a.end(), heavier);
+        std::stable_sort(ids_b.begin(), ids_b.end(), heavier);
+        snake(ids_a, 0, cus);
+        snake(ids_b, 0, cus);
+    } else if (!ids_a.empty()) {
         unsigned long long bytes = 0;
-        for (int i : ids_a) bytes += jobs[i].src_size;
+        std::vector<unsigned int> sizes(ids_a.size());
+        for (size_t k = 0; k < ids_a.size(); ++k) { sizes[k] = jobs[ids_a[k]].src_size; bytes += sizes[k]; }
         p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
-        // ids_a is sorted by size: the multi-pass streams are a prefix of it
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
-        const int force = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
-        size_t k_best = 0;
-        if (force > 0) k_best = ids_a.size();
-        else if (force == 0) {
-            double best = 0, head = 0;
-            for (size_t k = 0; k <= ids_a.size(); ++k) {
-                const double bk = k < ids_a.size() ? (double)jobs[ids_a[k]].src_size : 0.0;
-                const double rest = (double)bytes - head;
-                const double cost = SQOA_DP_COST * head + (SQOA_DP_SOLO * bk > rest ? SQOA_DP_SOLO * bk : rest);
-                if (k == 0 || cost < best) { best = cost; k_best = k; }
-                if (k == ids_a.size() || jobs[ids_a[k]].src_size < SQOA_DP_MIN_BYTES) break;
-                head += bk;
-            }
-        }
-        for (size_t k = 0; k < k_best; ++k) {
+        const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
+        std::vector<int> order(ids_a.size());
+        int n_multi = 0;
+        int rc = sqoa_hip_decode_route(sizes.data(), (int)sizes.size(), cus, mode, order.data(), &n_multi);
+        if (rc) return rc;
+        std::vector<int> sorted(ids_a.size());
+        for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
+        ids_a.swap(sorted);
+        for (int k = 0; k < n_multi; ++k) {
             const int i = ids_a[k];
             uint32_t nc, per;
             sqoa_dp_layout(jobs[i].src_size, &nc, &per, &dp_row_bytes);
-            if (dp_rows + nc > 0xffffffffull) break;
+            if (dp_rows + nc > 0xffffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
             const uint32_t img = (uint32_t)dp_images.size();
             dp_images.push_back({i, (uint32_t)dp_rows, nc, 0u});
             for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});

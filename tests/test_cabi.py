@@ -79,3 +79,45 @@ def test_encode_bound_matches_reference_formula():
         raw = w * h * (ch + 1) + 14 + 8 + 1
         assert seqoia_amd.encode_bound(seqoia_amd.Desc(w, h, c, 0, 0)) == (raw + 255) // 256 * 256
     assert seqoia_amd.encode_bound(seqoia_amd.Desc(0, 1, 4, 0, 0)) == 0
+
+
+def _route(sizes, cus=256, mode=0):
+    import ctypes as C
+    lib = seqoia_amd._lib.load()
+    n = len(sizes)
+    arr = (C.c_uint * max(n, 1))(*sizes)
+    order = (C.c_int * max(n, 1))()
+    k = C.c_int(-1)
+    assert lib.sqoa_hip_decode_route(arr, n, cus, mode, order, C.byref(k)) == 0
+    return list(order[:n]), k.value
+
+
+def test_decode_route_is_a_permutation_and_picks_the_streams_that_would_outlast_the_batch():
+    """The host-side choice between one workgroup per stream and the three chip-wide passes."""
+    mb = 1 << 20
+    # the headline batch: 1024 equal streams stay one workgroup each
+    order, k = _route([2600000] * 1024)
+    assert k == 0 and sorted(order) == list(range(1024))
+    # a lone stream, and a handful: all multi-pass, largest first
+    assert _route([2600000]) == ([0], 1)
+    order, k = _route([mb, 3 * mb, 2 * mb, 5 * mb])
+    assert k == 4 and order == [3, 1, 2, 0]
+    # tiny streams never take the passes (the launches cost more than the decode)
+    assert _route([4000] * 8)[1] == 0
+    # one screenshot among thousands of small images (BASELINE configs[4] shape): only the large ones
+    rng = np.random.default_rng(5)
+    sizes = [int(x) for x in rng.integers(20_000, 400_000, 4000)] + [20 * mb, 19 * mb, 9 * mb]
+    order, k = _route(sizes)
+    assert sorted(order) == list(range(len(sizes)))
+    assert k == 3 and order[:3] == [4000, 4001, 4002]
+    # forced modes
+    assert _route(sizes, mode=-1)[1] == 0 and _route(sizes, mode=1)[1] == len(sizes)
+    # the one-workgroup-per-stream part: largest first in runs of `cus`, every second run reversed
+    order, k = _route(list(range(100000, 100000 + 40 * 1000, 1000)), cus=8, mode=-1)
+    s = [100000 + 1000 * i for i in order]
+    assert s[:8] == sorted(s[:8], reverse=True) and s[8:16] == sorted(s[8:16]) and s[16:24] == sorted(s[16:24], reverse=True)
+    assert max(s[8:16]) <= min(s[:8]) and max(s[16:24]) <= min(s[8:16])
+    # empty plan and bad arguments
+    assert _route([]) == ([], 0)
+    import ctypes as C
+    assert seqoia_amd._lib.load().sqoa_hip_decode_route(None, 1, 256, 0, None, None) != 0
