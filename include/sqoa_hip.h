@@ -105,6 +105,12 @@ int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, siz
  * bytes, `cus` = compute units of the device (256), `mode` 0 = cost model, -1 = never multi-pass, 1 = always. */
 int sqoa_hip_decode_route(const unsigned int *src_sizes, int n, int cus, int mode, int *order, int *n_multipass);
 
+/* The same for an encode plan's SQOA-native images (`pixels[i]` = width * height): order[0 .. *n_strip_images) = the images the
+ * plan cuts into strips on the device (one image is otherwise one workgroup = one compute unit; strips[k] = how many strips
+ * order[k] gets), the rest in dispatch order.  SQOA_HIP_STRIPS=0 / =1 in the environment forces never / every image that is
+ * large enough; a plan that holds strip jobs of the caller's own (SQOA_HIP_JOB_*) cuts nothing. */
+int sqoa_hip_encode_route(const unsigned long long *pixels, int n, int cus, int mode, int *order, int *strips, int *n_strip_images);
+
 int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_plan **out);
 void sqoa_hip_plan_destroy(sqoa_hip_plan *plan);
 

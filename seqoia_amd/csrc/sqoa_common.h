@@ -23,7 +23,17 @@ struct sqoa_dp_tables {
     void* d_images; int n_images;   // dp_image rows: the multi-pass images, = the first n_images of the plan's id list
     void* d_wgs; int n_wgs;         // dp_wg rows: one per workgroup of a pass
     void* d_tab;                    // dp_chunk rows: one per chunk
-    void* d_flags;                  // one word per image: 0 not looked at, 1 wave path, 2 left to the other kernels
+    void* d_flags;                  // one word per image, written by pass 1: 1 wave path, 2 left to the other kernels
+};
+
+// Tables of the strip encode of few large images (sqoa_strips.hip); built by the plan (sqoa_runtime.hip).
+struct sqoa_st_tables {
+    void* d_images; int n_images;   // st_image rows: the images cut into strips, = the first n_images of the plan's SQOA id list
+    void* d_strips; int n_strips;   // st_strip rows: (image, nominal cut) per strip row
+    void* d_cuts;                   // one word per strip row: the pixel the strip starts at, or none
+    void* d_jobs; void* d_ids; void* d_results;   // strip jobs, their id list (-1: skipped row), their result rows
+    void* d_offsets;                // n_strips + 1 prefix sums of the strips' stream lengths
+    void* d_ws; size_t ws_bytes;    // the strips' output slots
 };
 
 namespace sqoa {

@@ -589,8 +589,7 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
     const dp_wg* wg = (const dp_wg*)d_wgs;
     dp_chunk* tab = (dp_chunk*)d_tab;
     uint32_t* fl = (uint32_t*)d_flags;
-    hipError_t e = hipMemsetAsync(fl, 0, sizeof(uint32_t) * (size_t)n_images, stream);
-    if (e != hipSuccess) return e;
+    // (no initialisation of the flags: pass 1's first workgroup of every image writes its flag before anything reads it)
     hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
     hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(64), 0, stream, im, tab, fl);
     hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];
+    if (jid < 0) return;   // a skipped row of a strip table (sqoa_strips.hip)
     const sqoa_hip_job job = jobs[jid];
 
     const uint32_t N = job.desc.width * job.desc.height;

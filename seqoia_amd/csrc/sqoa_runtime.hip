@@ -19,6 +19,8 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
+extern "C" void sqoa_st_layout(size_t* image_row, size_t* strip_row);
 extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes);
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
@@ -32,6 +34,22 @@ extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* c
 #endif
 #ifndef SQOA_DP_SOLO
 #define SQOA_DP_SOLO (550.0 * 1.25)   // R / r, x 1.25: a stream that shares its CU with other streams is slower than alone
+#endif
+// The same for the encoder (sqoa_strips.hip): an image alone runs at r = 1.8 Mpixel / ms, the chip at R = 670 Mpixel / ms;
+// cut into strips an image costs 1.8 x as much of the chip's time (the cut search, a prologue per strip, one more copy of the
+// stream).  tools/time_few_encode.py, 1024x1024 images: one 0.038 against 0.587 ms, 64: 0.21 / 0.63, 256: 0.68 / 0.67,
+// 1024: 2.70 / 1.52 ms; one 3840x2160 image 0.060 against 4.56 ms.
+#ifndef SQOA_ST_COST
+#define SQOA_ST_COST 1.8
+#endif
+#ifndef SQOA_ST_SOLO
+#define SQOA_ST_SOLO (385.0 * 1.25)
+#endif
+#ifndef SQOA_ST_MIN_PX
+#define SQOA_ST_MIN_PX 16384u      // pixels per strip, at least (32 sub-tiles: four per wave)
+#endif
+#ifndef SQOA_ST_WGS
+#define SQOA_ST_WGS 2048u          // strips aimed at per launch: two rounds of workgroups on the chip
 #endif
 #ifndef SQOA_DP_MIN_BYTES
 #define SQOA_DP_MIN_BYTES (16u << 10)
@@ -63,6 +81,8 @@ struct sqoa_hip_plan {
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
+    sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // encode: the few large images cut into strips
+    size_t st_images_cap = 0, st_strips_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;       // recorded behind the kernels of the most recent launch, on whatever stream it used
@@ -220,6 +240,41 @@ int sqoa_hip_decode_route(const unsigned int* src_sizes, int n, int cus, int mod
     return 0;
 }
 
+// The same choice for an encode plan's SQOA-native images: order[0 .. *n_strip_images) = the images cut into strips (largest
+// first; strips[k] = how many for order[k]), the rest one workgroup each.  `pixels[i]` = width * height.
+int sqoa_hip_encode_route(const unsigned long long* pixels, int n, int cus, int mode, int* order, int* strips, int* n_strip_images) {
+    if (!pixels || !order || !strips || !n_strip_images || n < 0 || cus <= 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_encode_route: bad arguments");
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; ++i) ids[i] = i;
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return pixels[a] > pixels[b]; });
+    double all = 0;
+    for (int i = 0; i < n; ++i) all += (double)pixels[i];
+    size_t k_best = 0;
+    double head_best = 0;
+    if (mode >= 0) {
+        double best = 0, head = 0;
+        for (size_t k = 0; k <= (size_t)n; ++k) {
+            const double bk = k < (size_t)n ? (double)pixels[ids[k]] : 0.0;
+            const double rest = all - head;
+            const double cost = SQOA_ST_COST * head + (SQOA_ST_SOLO * bk > rest ? SQOA_ST_SOLO * bk : rest);
+            if (mode > 0 || k == 0 || cost < best) { best = cost; k_best = k; head_best = head; }
+            if (k == (size_t)n || pixels[ids[k]] < 2ull * SQOA_ST_MIN_PX || pixels[ids[k]] > 0xffffffffull) break;
+            head += bk;
+        }
+    }
+    // pixels per strip: SQOA_ST_WGS strips over all the images cut, SQOA_ST_MIN_PX at least
+    double per = head_best / SQOA_ST_WGS;
+    if (per < SQOA_ST_MIN_PX) per = SQOA_ST_MIN_PX;
+    for (size_t k = 0; k < (size_t)n; ++k) {
+        double s = k < k_best ? (double)pixels[ids[k]] / per : 0.0;
+        strips[k] = k < k_best ? (s < 2.0 ? 2 : (int)s) : 0;
+    }
+    snake(ids, k_best, cus);
+    memcpy(order, ids.data(), sizeof(int) * (size_t)n);
+    *n_strip_images = (int)k_best;
+    return 0;
+}
+
 // Classify jobs, fill the pre-launch result rows and the per-variant id lists, upload all three.
 static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     std::vector<sqoa_hip_result> init(n ? n : 1);
@@ -246,15 +301,39 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     std::vector<dp_image_row> dp_images;
     std::vector<dp_wg_row> dp_wgs;
     size_t dp_rows = 0, dp_row_bytes = 32;
+    struct st_image_row { int jid; uint32_t first, nstrips, npx; unsigned long long ws; };   // = sqoa::st_image / st_strip (sqoa_strips.hip)
+    struct st_strip_row { uint32_t img, k; };
+    std::vector<st_image_row> st_images;
+    std::vector<st_strip_row> st_strips;
+    size_t st_ws = 0;
     if (p->kind == SQOA_HIP_ENCODE) {
-        // largest image first (see sqoa_hip_decode_route), then boustrophedon
-        auto heavier = [&](int a, int b) {
-            return (unsigned long long)jobs[a].desc.width * jobs[a].desc.height > (unsigned long long)jobs[b].desc.width * jobs[b].desc.height;
-        };
-        std::stable_sort(ids_a.begin(), ids_a.end(), heavier);
-        std::stable_sort(ids_b.begin(), ids_b.end(), heavier);
-        snake(ids_a, 0, cus);
+        // largest image first (see sqoa_hip_decode_route), then boustrophedon; the QOI-compat list as it is
+        auto npx = [&](int i) { return (unsigned long long)jobs[i].desc.width * jobs[i].desc.height; };
+        std::stable_sort(ids_b.begin(), ids_b.end(), [&](int a, int b) { return npx(a) > npx(b); });
         snake(ids_b, 0, cus);
+        if (!ids_a.empty()) {
+            // SQOA_HIP_STRIPS=0 / =1 in the environment: never / every image that is large enough (tests and measurements).  A
+            // caller that sends strip jobs of its own (sqoa_host.c) has done the cutting already.
+            const char* knob = getenv("SQOA_HIP_STRIPS");
+            int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
+            std::vector<unsigned long long> px(ids_a.size());
+            for (size_t k = 0; k < ids_a.size(); ++k) { px[k] = npx(ids_a[k]); if (jobs[ids_a[k]].reserved) mode = -1; }
+            std::vector<int> order(ids_a.size()), nst(ids_a.size());
+            int n_cut = 0;
+            int rc = sqoa_hip_encode_route(px.data(), (int)px.size(), cus, mode, order.data(), nst.data(), &n_cut);
+            if (rc) return rc;
+            std::vector<int> sorted(ids_a.size());
+            for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
+            ids_a.swap(sorted);
+            for (int k = 0; k < n_cut; ++k) {
+                const int i = ids_a[k];
+                const uint32_t ch = (jobs[i].desc.channels < 3 ? 1u : 3u) + ((jobs[i].desc.channels & 1) ? 0u : 1u);
+                const uint32_t first = (uint32_t)st_strips.size(), ns = (uint32_t)nst[k];
+                st_images.push_back({i, first, ns, (uint32_t)npx(i), (unsigned long long)st_ws});   // (.ws: offset, the base is added below)
+                for (uint32_t q = 0; q < ns; ++q) st_strips.push_back({(uint32_t)k, q});
+                st_ws += (((size_t)npx(i) * (ch + 1) + 255) & ~(size_t)255) + (size_t)ns * 512 + 512;
+            }
+        }
     } else if (!ids_a.empty()) {
         unsigned long long bytes = 0;
         std::vector<unsigned int> sizes(ids_a.size());
@@ -293,14 +372,41 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
     p->dp.n_images = (int)dp_images.size();
     p->dp.n_wgs = (int)dp_wgs.size();
+    auto grow = [&](void** d, size_t* cap, size_t rows, size_t row_bytes) -> hipError_t {
+        if (rows <= *cap) return hipSuccess;
+        if (*d) { hipError_t e2 = hipFree(*d); *d = nullptr; *cap = 0; if (e2 != hipSuccess) return e2; }
+        hipError_t e2 = hipMalloc(d, rows * row_bytes);
+        if (e2 == hipSuccess) *cap = rows;
+        return e2;
+    };
+    p->st.n_images = (int)st_images.size();
+    p->st.n_strips = (int)st_strips.size();
+    if (!st_images.empty()) {
+        const size_t ni = st_images.size(), ns = st_strips.size();
+        e = grow(&p->st.d_images, &p->st_images_cap, ni, sizeof(st_image_row));
+        if (e == hipSuccess && ns > p->st_strips_cap) {   // the per-strip tables share one capacity
+            void** tabs[6] = {&p->st.d_strips, &p->st.d_cuts, &p->st.d_jobs, &p->st.d_ids, &p->st.d_results, &p->st.d_offsets};
+            const size_t row[6] = {sizeof(st_strip_row), sizeof(uint32_t), sizeof(sqoa_hip_job), sizeof(int), sizeof(sqoa_hip_result), sizeof(unsigned long long)};
+            p->st_strips_cap = 0;
+            for (int t = 0; t < 6 && e == hipSuccess; ++t) {
+                if (*tabs[t]) { hipFree(*tabs[t]); *tabs[t] = nullptr; }
+                e = hipMalloc(tabs[t], (ns + 1) * row[t]);
+            }
+            if (e == hipSuccess) p->st_strips_cap = ns;
+        }
+        if (e == hipSuccess) e = grow(&p->st.d_ws, &p->st.ws_bytes, st_ws, 1);
+        if (e != hipSuccess) {
+            p->st.n_images = p->st.n_strips = 0;
+            return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan: tables and workspace of the strip encode", e);
+        }
+        for (auto& r : st_images) r.ws += (unsigned long long)(uintptr_t)p->st.d_ws;
+        if ((e = hipMemcpy(p->st.d_images, st_images.data(), sizeof(st_image_row) * ni, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->st.d_strips, st_strips.data(), sizeof(st_strip_row) * ns, hipMemcpyHostToDevice)) != hipSuccess) {
+            p->st.n_images = p->st.n_strips = 0;
+            return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the strip encode, upload", e);
+        }
+    }
     if (!dp_images.empty()) {
-        auto grow = [&](void** d, size_t* cap, size_t rows, size_t row_bytes) -> hipError_t {
-            if (rows <= *cap) return hipSuccess;
-            if (*d) { hipError_t e2 = hipFree(*d); *d = nullptr; *cap = 0; if (e2 != hipSuccess) return e2; }
-            hipError_t e2 = hipMalloc(d, rows * row_bytes);
-            if (e2 == hipSuccess) *cap = rows;
-            return e2;
-        };
         if ((e = grow(&p->dp.d_flags, &p->dp_flags_cap, dp_images.size(), sizeof(uint32_t))) != hipSuccess ||
             (e = grow(&p->dp.d_images, &p->dp_images_cap, dp_images.size(), sizeof(dp_image_row))) != hipSuccess ||
             (e = grow(&p->dp.d_wgs, &p->dp_wgs_cap, dp_wgs.size(), sizeof(dp_wg_row))) != hipSuccess ||
@@ -360,6 +466,8 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->d_results) hipFree(p->d_results);
     if (p->d_init) hipFree(p->d_init);
     if (p->d_ids) hipFree(p->d_ids);
+    for (void* d : {p->st.d_images, p->st.d_strips, p->st.d_cuts, p->st.d_jobs, p->st.d_ids, p->st.d_results, p->st.d_offsets, p->st.d_ws})
+        if (d) hipFree(d);
     if (p->dp.d_images) hipFree(p->dp.d_images);
     if (p->dp.d_wgs) hipFree(p->dp.d_wgs);
     if (p->dp.d_tab) hipFree(p->dp.d_tab);
@@ -375,7 +483,8 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);  // the calling thread's current device may be another one
     HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
     if (p->kind == SQOA_HIP_ENCODE) {
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids, p->n_sqoa, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode_strips(p->d_jobs, p->d_results, &p->st, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->st.n_images, p->n_sqoa - p->st.n_images, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
         HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
@@ -548,6 +657,11 @@ __global__ void fnv_kernel(const unsigned long long* __restrict__ ptrs, const ui
 }
 
 }  // namespace sqoa
+
+extern "C" hipError_t sqoa_launch_pack_offsets(const sqoa_hip_result* d_res, int n, unsigned long long* d_offsets, hipStream_t stream) {
+    hipLaunchKernelGGL(sqoa::pack_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_res, n, d_offsets);
+    return hipGetLastError();
+}
 
 extern "C" {
 

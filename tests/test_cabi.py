@@ -121,3 +121,31 @@ def test_decode_route_is_a_permutation_and_picks_the_streams_that_would_outlast_
     assert _route([]) == ([], 0)
     import ctypes as C
     assert seqoia_amd._lib.load().sqoa_hip_decode_route(None, 1, 256, 0, None, None) != 0
+
+
+def test_encode_route_cuts_the_images_that_would_outlast_the_batch():
+    """The host-side choice between one workgroup per image and strips over the whole chip (sqoa_strips.hip)."""
+    import ctypes as C
+    lib = seqoia_amd._lib.load()
+
+    def route(px, cus=256, mode=0):
+        n = len(px)
+        arr = (C.c_ulonglong * max(n, 1))(*px)
+        order, strips, k = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))(), C.c_int(-1)
+        assert lib.sqoa_hip_encode_route(arr, n, cus, mode, order, strips, C.byref(k)) == 0
+        return list(order[:n]), list(strips[:n]), k.value
+
+    mp = 1 << 20
+    order, strips, k = route([mp] * 1024)                      # the headline batch: one workgroup per image
+    assert k == 0 and sorted(order) == list(range(1024)) and not any(strips)
+    order, strips, k = route([mp])                             # a lone image: 64 strips of 16 384 pixels
+    assert (order, k) == ([0], 1) and strips == [64]
+    order, strips, k = route([3840 * 2160])                    # a lone screenshot: about 2048 strips / 4 rounds... at least a few hundred
+    assert k == 1 and 400 <= strips[0] <= 2048
+    order, strips, k = route([64 * 64] * 100)                  # icons: too small to cut
+    assert k == 0
+    sizes = [300 * 300] * 5000 + [3840 * 2160, 2560 * 1440]    # screenshots among thousands of small images
+    order, strips, k = route(sizes)
+    assert k == 2 and order[:2] == [5000, 5001] and strips[0] > strips[1] >= 2 and sorted(order) == list(range(len(sizes)))
+    assert route(sizes, mode=-1)[2] == 0 and route(sizes, mode=1)[2] == len(sizes)
+    assert lib.sqoa_hip_encode_route(None, 1, 256, 0, None, None, None) != 0

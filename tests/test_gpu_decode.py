@@ -392,6 +392,32 @@ def test_plans_replay_from_a_hip_graph(sq, orc):
             want = o.encode(orc.synth(w, h, 4, "mixed", seed, k), w, h, 4, 0)
             assert bytes(enc.out[k, : int(r["len"][k])].cpu().numpy()) == want, (seed, k)
     dec.close()
+    # the decode plan in a graph of its own, on both routes of the wave decoder (the three-pass route is five kernels and two
+    # scan kernels per launch, all of them captured)
+    import os
+    sq.synth(px, "mixed", seed=1, img0=0)
+    enc.launch()
+    res = enc.results()
+    for knob in ("0", "1"):
+        os.environ["SQOA_HIP_MULTIPASS"] = knob
+        try:
+            dec = sq.DecodePlan(enc.out, res["len"], w, h, 4)
+        finally:
+            del os.environ["SQOA_HIP_MULTIPASS"]
+        with torch.cuda.stream(side):
+            dec.launch(side.cuda_stream)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=side):
+            dec.launch(side.cuda_stream)
+        for _ in range(2):
+            dec.out.zero_()
+            torch.cuda.synchronize()
+            g2.replay()
+            torch.cuda.synchronize()
+            assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, px), knob
+        dec.close()
     enc.close()
 
 

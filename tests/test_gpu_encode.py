@@ -490,3 +490,50 @@ def test_legacy_encode_strip_jobs(sq, orc):
     body = bytes(out[0, : int(res["len"][0])].cpu().numpy()) + bytes(out[1, : int(res["len"][1])].cpu().numpy())
     assert want[:15] + body == want
     plan.close()
+
+
+@pytest.mark.parametrize("knob", ["1", ""])
+def test_batch_encode_cuts_large_images_into_strips_on_the_device(sq, orc, monkeypatch, knob):
+    """A plan with few large images cuts them into strips on the device (sqoa_strips.hip): the cut search (forward to a
+    pixel that differs from its predecessor, up to the next nominal cut), cuts that do not exist (one-colour stretches),
+    the strips' streams packed behind the header at the image's own slot.  Byte identity with the reference; the same
+    plan with SQOA_HIP_STRIPS=0 gives the same bytes."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(78)
+    w, h = 640, 480  # 307 200 pixels: 18 nominal strips of 16 384 when forced
+    cases = []
+    for ch in (4, 3, 2, 1, 6):
+        stride = sq.stride_channels(ch)
+        px = rng.integers(0, 256, size=(w * h, stride), dtype=np.uint8)
+        for k in range(1, 18):  # runs across every nominal cut position (and a few elsewhere), around the 61 / 512 boundaries
+            a = w * h * k // 18 - int(rng.integers(0, 700))
+            px[a:a + int(rng.choice([3, 62, 63, 511, 512, 513, 1500, 40000]))] = px[a]
+        cases.append((f"runs_at_cuts_ch{ch}", px.reshape(-1), ch))
+    cases.append(("one_colour", np.full(w * h * 4, 37, dtype=np.uint8), 4))
+    cases.append(("default_pixel", np.tile(np.array([0, 0, 0, 255], dtype=np.uint8), w * h), 4))
+    grad = (np.arange(w * h, dtype=np.uint32)[:, None] >> np.array([3, 9, 14, 30], dtype=np.uint32)).astype(np.uint8)
+    cases.append(("gradient_with_long_runs", grad.reshape(-1), 4))
+    half = np.concatenate([np.full(w * h * 2, 200, dtype=np.uint8), rng.integers(0, 256, size=w * h * 2, dtype=np.uint8)])
+    cases.append(("flat_then_noise", half, 4))
+    cases.append(("icon_tile", orc.synth(w, h, 3, "icon", 9, 1), 3))
+    cases.append(("small_next_to_large", orc.synth(64, 64, 4, "mixed", 9, 2), 4))   # (too small to cut: one workgroup)
+    wants = [o.encode(px, (64 if name.startswith("small") else w), (64 if name.startswith("small") else h), ch, 0) for name, px, ch in cases]
+    got = {}
+    for setting in (knob, "0"):
+        monkeypatch.setenv("SQOA_HIP_STRIPS", setting)
+        images = [(torch.from_numpy(px).cuda(), sq.Desc(64 if name.startswith("small") else w, 64 if name.startswith("small") else h, ch, 0, 0))
+                  for name, px, ch in cases]
+        plan = sq.EncodeList(images)
+        for _ in range(2):  # (a second launch of the same plan: the strip tables are rebuilt on the device every time)
+            plan.launch()
+        res = plan.results()
+        got[setting] = plan.streams()
+        assert (res["status"] == 0).all(), (setting, res["status"].tolist())
+        blob, offsets = plan.pack()
+        assert int(offsets[-1]) == sum(len(x) for x in wants)
+        plan.close()
+    for k, (name, px, ch) in enumerate(cases):
+        assert got[knob][k] == wants[k], (name, "strips")
+        assert got["0"][k] == wants[k], (name, "one workgroup")
