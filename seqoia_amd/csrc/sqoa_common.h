@@ -22,6 +22,7 @@
 struct sqoa_dp_tables {
     void* d_images; int n_images;   // dp_image rows: the multi-pass images, = the first n_images of the plan's id list
     void* d_wgs; int n_wgs;         // dp_wg rows: one per workgroup of a pass
+    unsigned per;                   // chunks a workgroup takes
     void* d_tab;                    // dp_chunk rows: one per chunk
     void* d_flags;                  // one word per image, written by pass 1: 1 wave path, 2 left to the other kernels
 };

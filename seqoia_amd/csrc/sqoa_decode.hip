@@ -526,7 +526,7 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, hipStream_t stream);
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, hipStream_t stream);
 
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
@@ -536,7 +536,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n <= 0) return hipSuccess;
     const int n_multi = dp ? dp->n_images : 0;
     hipError_t e = hipSuccess;
-    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, stream);
+    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, stream);
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, d_results, stream);
     if (e != hipSuccess) return e;

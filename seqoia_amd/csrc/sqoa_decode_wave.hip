@@ -81,26 +81,42 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 
 
 // ---- chip-wide decode of few large streams: the tables of the three passes (MODE 1..3 of decode_wave_kernel) -----------------
-struct dp_image { int jid; uint32_t tab_off, nchunks, pad; };          // one multi-pass image: its job, its rows of the chunk table
+struct dp_image { int jid; uint32_t tab_off, nchunks, nwgs; };         // one multi-pass image: its job, its rows of the table (one per workgroup)
 struct dp_wg { uint32_t img, chunk0; };                                 // one workgroup of a pass: image and first chunk
-struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };   // what the LDS chain carries, per chunk, in HBM
-constexpr uint32_t DP_CHUNKS_PER_WG = 16;
+// What the LDS chain carries, per workgroup (DP_CHUNKS_PER_WG chunks), in HBM: the composite of its chunks' transition functions,
+// pixel counts and transforms (written by passes 1 and 2), and what enters its first chunk (written by the two scans).
+struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };
+constexpr uint32_t DP_CHUNKS_PER_WG_MIN = 16, DP_CHUNKS_PER_WG_MAX = 64;   // chunks per workgroup of a pass: the plan picks (sqoa_dp_layout)
 
-// Entry state of every chunk: the chunks' transition functions composed in stream order, 64 chunks per step (one wave per image).
-__global__ __launch_bounds__(64) void dp_scan_state(const dp_image* __restrict__ images, dp_chunk* __restrict__ tabs, const uint32_t* __restrict__ flags) {
-    const int lane = lane_id();
+// The two scans between the passes: one workgroup of 1024 threads per image, every thread a contiguous run of the image's
+// table rows -- its run composed serially (independent loads), one scan over the 1024 run totals (DPP inside the waves, LDS
+// across the 16 of them), its run walked again with the prefix.  (One wave stepping through 64 chunks at a time was a chain of
+// dependent load latencies: 0.6 ms of the 0.69 ms a lone 3840x2160 stream took.)
+constexpr int DP_SCAN_THREADS = 1024;
+
+// Entry state of every chunk: the chunks' transition functions composed in stream order.
+__global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_state(const dp_image* __restrict__ images, dp_chunk* __restrict__ tabs, const uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_lo[DP_SCAN_THREADS / 64], s_hi[DP_SCAN_THREADS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const dp_image im = images[blockIdx.x];
     if (flags[blockIdx.x] != 1u) return;
     dp_chunk* tab = tabs + im.tab_off;
-    uint32_t st = ST_N;   // stream start (seqoia.h:773-775)
-    for (uint32_t base = 0; base < im.nchunks; base += 64) {
-        const uint32_t c = base + lane;
-        Fn F{ID_LO, ID_HI};
-        if (c < im.nchunks) { F.lo = tab[c].g_lo; F.hi = tab[c].g_hi; }
-        const Fn Fi = wave_compose_scan(F);
-        const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
-        if (c < im.nchunks) tab[c].st_in = apply(Fx, st);
-        st = apply(Fn{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)}, st);
+    const uint32_t per = (im.nwgs + DP_SCAN_THREADS - 1) / DP_SCAN_THREADS;
+    const uint32_t c0 = t * per < im.nwgs ? t * per : im.nwgs, c1 = c0 + per < im.nwgs ? c0 + per : im.nwgs;
+    Fn F{ID_LO, ID_HI};
+#pragma unroll 4
+    for (uint32_t c = c0; c < c1; ++c) F = compose(Fn{tab[c].g_lo, tab[c].g_hi}, F);
+    const Fn Fi = wave_compose_scan(F);
+    if (lane == 63u) { s_lo[wv] = Fi.lo; s_hi[wv] = Fi.hi; }
+    __syncthreads();
+    Fn P{ID_LO, ID_HI};
+    for (uint32_t k = 0; k < wv; ++k) P = compose(Fn{s_lo[k], s_hi[k]}, P);
+    const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
+    uint32_t st = apply(compose(Fx, P), ST_N);   // ST_N: stream start (seqoia.h:773-775)
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Fn G{tab[c].g_lo, tab[c].g_hi};
+        tab[c].st_in = st;
+        st = apply(G, st);
     }
 }
 
@@ -115,40 +131,49 @@ SQOA_DEV Xf wave_xf_scan(Xf T);
 
 // Pixel position and entering pixel of every chunk: prefix sum of the pixel counts (saturating at N: counts of crafted streams
 // overflow 32 bits otherwise) and prefix composition of the transforms.
-__global__ __launch_bounds__(64) void dp_scan_pixels(const sqoa_hip_job* __restrict__ jobs, const dp_image* __restrict__ images, dp_chunk* __restrict__ tabs,
-                                                     const uint32_t* __restrict__ flags) {
-    const int lane = lane_id();
+__global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_pixels(const sqoa_hip_job* __restrict__ jobs, const dp_image* __restrict__ images,
+                                                                  dp_chunk* __restrict__ tabs, const uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_c[DP_SCAN_THREADS / 64], s_v[DP_SCAN_THREADS / 64], s_a[DP_SCAN_THREADS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const dp_image im = images[blockIdx.x];
     if (flags[blockIdx.x] != 1u) return;
     gcptr8 src = (gcptr8)jobs[im.jid].src;
     const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
     const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
     const uint32_t N = hw * hh;
+    auto sat = [&](uint32_t a, uint32_t b) { const uint32_t x = a + b; return x > N ? N : x; };   // (a, b <= N < 2^31)
     dp_chunk* tab = tabs + im.tab_off;
-    uint32_t pos = 0, px = kPxInit;
-    for (uint32_t base = 0; base < im.nchunks; base += 64) {
-        const uint32_t c = base + lane;
-        const bool live = c < im.nchunks;
-        const uint32_t cnt = live ? tab[c].ctot : 0u;
-        Xf T{live ? tab[c].tv : 0u, live ? tab[c].tabs : 0u};
-        uint32_t v = cnt;
-        v = dp_sat_step<DPP_ROW_SHR + 1, 0xf>(v, N);
-        v = dp_sat_step<DPP_ROW_SHR + 2, 0xf>(v, N);
-        v = dp_sat_step<DPP_ROW_SHR + 4, 0xf>(v, N);
-        v = dp_sat_step<DPP_ROW_SHR + 8, 0xf>(v, N);
-        v = dp_sat_step<DPP_ROW_BCAST15, 0xa>(v, N);
-        v = dp_sat_step<DPP_ROW_BCAST31, 0xc>(v, N);
-        const uint32_t before = shift_up1(v, 0u);                      // pixels of the chunks below mine in this group (saturated)
-        const Xf Ti = wave_xf_scan(T);
-        const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
-        if (live) {
-            const uint32_t p = pos + before;
-            tab[c].pos_in = p > N ? N : p;
-            tab[c].px_in = xf_apply(Tx, px);
-        }
-        const uint32_t tot = bcast_lane(v, 63);
-        pos = pos + tot > N ? N : pos + tot;
-        px = xf_apply(Xf{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)}, px);
+    const uint32_t per = (im.nwgs + DP_SCAN_THREADS - 1) / DP_SCAN_THREADS;
+    const uint32_t c0 = t * per < im.nwgs ? t * per : im.nwgs, c1 = c0 + per < im.nwgs ? c0 + per : im.nwgs;
+    uint32_t cnt = 0;
+    Xf T{0u, 0u};
+#pragma unroll 4
+    for (uint32_t c = c0; c < c1; ++c) {
+        cnt = sat(cnt, tab[c].ctot);
+        T = xf_then(T, Xf{tab[c].tv, tab[c].tabs});
+    }
+    uint32_t v = cnt;
+    v = dp_sat_step<DPP_ROW_SHR + 1, 0xf>(v, N);
+    v = dp_sat_step<DPP_ROW_SHR + 2, 0xf>(v, N);
+    v = dp_sat_step<DPP_ROW_SHR + 4, 0xf>(v, N);
+    v = dp_sat_step<DPP_ROW_SHR + 8, 0xf>(v, N);
+    v = dp_sat_step<DPP_ROW_BCAST15, 0xa>(v, N);
+    v = dp_sat_step<DPP_ROW_BCAST31, 0xc>(v, N);
+    const Xf Ti = wave_xf_scan(T);
+    if (lane == 63u) { s_c[wv] = v; s_v[wv] = Ti.v; s_a[wv] = Ti.abs; }
+    __syncthreads();
+    uint32_t pos = 0;
+    Xf P{0u, 0u};
+    for (uint32_t k = 0; k < wv; ++k) { pos = sat(pos, s_c[k]); P = xf_then(P, Xf{s_v[k], s_a[k]}); }
+    pos = sat(pos, shift_up1(v, 0u));                                                  // pixels in front of my run (saturated)
+    uint32_t px = xf_apply(xf_then(P, Xf{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)}), kPxInit);   // pixel entering my run
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t n = tab[c].ctot;
+        const Xf Tc{tab[c].tv, tab[c].tabs};
+        tab[c].pos_in = pos;
+        tab[c].px_in = px;
+        pos = sat(pos, n);
+        px = xf_apply(Tc, px);
     }
 }
 
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results,
                                                              const dp_image* __restrict__ dp_images, const dp_wg* __restrict__ dp_wgs,
-                                                             dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags) {
+                                                             dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags, uint32_t dp_per) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
@@ -203,7 +228,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     gcptr8 src = (gcptr8)job.src;
     gptr8 out = (gptr8)job.dst;
     const uint32_t size = job.src_size;
-    dp_chunk* tab = MODE ? dp_tab + tab_off : nullptr;
+    // MODE > 0: this workgroup's row of the table; what enters its first chunk (the scans wrote it; MODE 0: the stream start)
+    dp_chunk* row = MODE ? dp_tab + tab_off + chunk_first / dp_per : nullptr;
+    __shared__ uint32_t s_wg[3][MODE ? DP_CHUNKS_PER_WG_MAX : 1];   // passes 1 and 2: per chunk of the workgroup, what goes into its row
+    uint32_t seed_st = ST_N, seed_pos = 0, seed_px = kPxInit;   // ST_N: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
+    if (MODE >= 2 && chunk_first) seed_st = bcast_first(row->st_in);
+    if (MODE == 3 && chunk_first) { seed_pos = bcast_first(row->pos_in); seed_px = bcast_first(row->px_in); }
 
     if (MODE >= 2 && threadIdx.x == 0) { s_abort = 0; s_path = dp_flags[img]; }   // what pass 1 (or pass 2: SQOA_OP_REF) decided
     if ((MODE == 0 || (MODE == 1 && chunk_first == 0)) && threadIdx.x == 0) {
@@ -269,8 +299,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const uint32_t chunks_len = size_a - 8;     // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
-    // the chunks this workgroup takes: all of them, or (MODE > 0) DP_CHUNKS_PER_WG from chunk_first on
-    const uint32_t chunk_end = MODE == 0 ? nchunks : (chunk_first + DP_CHUNKS_PER_WG < nchunks ? chunk_first + DP_CHUNKS_PER_WG : nchunks);
+    // the chunks this workgroup takes: all of them, or (MODE > 0) dp_per from chunk_first on
+    const uint32_t chunk_end = MODE == 0 ? nchunks : (chunk_first + dp_per < nchunks ? chunk_first + dp_per : nchunks);
     uint32_t bad = 0;
 
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
@@ -339,19 +369,21 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const bool g_const = G.lo == g0 * 0x01010101u && (G.hi & 0xffffu) == g0 * 0x0101u;
         unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
         DPHASE(0);
-        uint32_t st_in = ST_N;  // stream start: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
-        if constexpr (MODE == 0) {
-            if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
-            if (c > 0) {
+        uint32_t st_in = seed_st;
+        if constexpr (MODE == 1) {
+            if (lane == 0) { s_wg[0][c - chunk_first] = G.lo; s_wg[1][c - chunk_first] = G.hi; }
+            return 1u;
+        } else {   // inside the workgroup the chunks are chained through LDS in every mode
+            // An exit state that does not depend on the entry state is posted before the entry state is known.  That lets a
+            // wave run ahead of its successor, and the two-deep slots are safe only because the pixel chain below holds it
+            // back (a wave cannot finish chunk c + W before chunk c + 1 has been entered); pass 2 has no pixel chain.
+            const bool early = g_const && MODE != 2;
+            if (early && !last_chunk) post(my_parse, c + 1, g0, lane);
+            if (c > chunk_first) {
                 const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in);
                 if (rc) { bad |= rc >> 1; return 0u; }
             }
-            if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
-        } else if constexpr (MODE == 1) {
-            if (lane == 0) { tab[c].g_lo = G.lo; tab[c].g_hi = G.hi; }
-            return 1u;
-        } else {
-            if (c > 0) st_in = bcast_first(tab[c].st_in);
+            if (!early && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
         }
         DPHASE(1);
 
@@ -449,12 +481,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(3);
         // ---- 4. entry position / pixel from the chain, publish exits, store ------------------
         if constexpr (MODE == 2) {
-            if (lane == 0) { tab[c].ctot = ctot > N ? N : ctot; tab[c].tv = Tg.v; tab[c].tabs = Tg.abs; }
+            if (lane == 0) { s_wg[0][c - chunk_first] = ctot > N ? N : ctot; s_wg[1][c - chunk_first] = Tg.v; s_wg[2][c - chunk_first] = Tg.abs; }
             return 1u;
         }
-        uint32_t pos_in = 0, px_in = kPxInit;
-        if (MODE == 3 && c > 0) { pos_in = bcast_first(tab[c].pos_in); px_in = bcast_first(tab[c].px_in); }
-        if (MODE == 0 && c > 0) {
+        uint32_t pos_in = seed_pos, px_in = seed_px;
+        if (c > chunk_first) {
             // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
             // instructions in order), so it is there when the pixel word's tag is
             const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, &s_abort, px_in);
@@ -465,7 +496,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(4);
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-        if (MODE == 0 && !last_chunk && lane == 0) {
+        if (!last_chunk && lane == 0) {
             __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -559,6 +590,22 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         for (; go && c < nint; c += W) go = body(std::true_type{}, c);
     }
     for (; go && c < chunk_end; c += W) go = body(std::false_type{}, c);
+    if constexpr (MODE == 1 || MODE == 2) {   // the workgroup's chunks composed in stream order -> its row of the table
+        __syncthreads();
+        if (w == 0) {
+            const uint32_t nk = chunk_end - chunk_first;
+            const bool live = (uint32_t)lane < nk;
+            if constexpr (MODE == 1) {
+                const Fn Fi = wave_compose_scan(Fn{live ? s_wg[0][lane] : ID_LO, live ? s_wg[1][lane] : ID_HI});
+                if (lane == 63) { row->g_lo = Fi.lo; row->g_hi = Fi.hi; }
+            } else {
+                uint32_t v = live ? s_wg[0][lane] : 0u;   // (<= N each; 16 of them: no 32-bit overflow, N < 400 000 000)
+                v = wave_incl_scan(v);
+                const Xf Ti = wave_xf_scan(Xf{live ? s_wg[1][lane] : 0u, live ? s_wg[2][lane] : 0u});
+                if (lane == 63) { row->ctot = v > N ? N : v; row->tv = Ti.v; row->tabs = Ti.abs; }
+            }
+        }
+    }
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 #ifdef SQOA_TRACE
     if (threadIdx.x == 0) { unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull); for (int k = 0; k < 8; ++k) tr[k] = ph[k]; }
@@ -574,15 +621,16 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 #define SQOA_DEC_W 8
 #endif
     constexpr int W = SQOA_DEC_W;
-    hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u);
     return hipGetLastError();
 }
 
 // Few large streams: three passes over all their chunks with the whole chip (see decode_wave_kernel), two one-wave-per-image scans
 // in between.  `d_images` / `d_wgs` / `d_tab` / `d_flags`: the tables the plan built (sqoa_runtime.hip).
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, hipStream_t stream) {
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, hipStream_t stream) {
     if (n_images <= 0 || n_wgs <= 0) return hipSuccess;
+    if (per < sqoa::DP_CHUNKS_PER_WG_MIN || per > sqoa::DP_CHUNKS_PER_WG_MAX || per % 8u) return hipErrorInvalidValue;   // (8 waves take the chunks round-robin)
     using namespace sqoa;
     constexpr int W = 8;
     const dp_image* im = (const dp_image*)d_images;
@@ -590,20 +638,27 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
     dp_chunk* tab = (dp_chunk*)d_tab;
     uint32_t* fl = (uint32_t*)d_flags;
     // (no initialisation of the flags: pass 1's first workgroup of every image writes its flag before anything reads it)
-    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
-    hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(64), 0, stream, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
-    hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(64), 0, stream, d_jobs, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
+    hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
+    hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, d_jobs, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
     return hipGetLastError();
 }
 
-// What the plan needs to lay the pass tables out (sqoa_runtime.hip): rows of the chunk table and chunks per workgroup for a stream of
-// `src_size` bytes (the chunk area is what lies between header + start byte and the 8 end bytes, as in decode_wave_kernel).
-extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes) {
+// What the plan needs to lay the pass tables out (sqoa_runtime.hip): the chunks of a stream of `src_size` bytes (the chunk area is
+// what lies between header + start byte and the 8 end bytes, as in decode_wave_kernel), and -- for `total_chunks` over all the
+// multi-pass streams of a plan -- how many chunks a workgroup of a pass takes: few (many workgroups) while the chip is not
+// full, more when it is (inside a workgroup the chunks are chained through LDS, and a short chain is mostly ramp-up: 1024
+// images at 16 chunks per workgroup 9.2 ms).  One table row per workgroup.
+extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size) {
     const uint32_t area = src_size > 23u ? src_size - 23u : 0u;
-    const uint32_t nc = area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
-    *nchunks = nc;
-    *chunks_per_wg = sqoa::DP_CHUNKS_PER_WG;
-    *chunk_row_bytes = sizeof(sqoa::dp_chunk);
+    return area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
+}
+extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes) {
+    if (row_bytes) *row_bytes = sizeof(sqoa::dp_chunk);
+    unsigned long long per = (total_chunks / 4096ull + 7ull) & ~7ull;   // about 4096 workgroups: four rounds on the chip
+    if (per < sqoa::DP_CHUNKS_PER_WG_MIN) per = sqoa::DP_CHUNKS_PER_WG_MIN;
+    if (per > sqoa::DP_CHUNKS_PER_WG_MAX) per = sqoa::DP_CHUNKS_PER_WG_MAX;
+    return (uint32_t)per;
 }

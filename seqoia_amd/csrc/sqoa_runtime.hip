@@ -21,16 +21,18 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" void sqoa_st_layout(size_t* image_row, size_t* strip_row);
-extern "C" void sqoa_dp_layout(uint32_t src_size, uint32_t* nchunks, uint32_t* chunks_per_wg, size_t* chunk_row_bytes);
+extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
+extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes);
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
 // empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
-// 660 MB / ms for the chip; tools/time_few.py: 1024x1024 images, one 0.11 against 1.99 ms, 64: 0.64 against 2.15 ms, 256: 2.2
-// ms either way, 1024: 8.45 against 3.73 ms).  The plan sorts the streams by size and sends the k largest through the passes,
-// k minimising      SQOA_DP_COST * bytes(first k) + max(SQOA_DP_SOLO * bytes(stream k), bytes(rest))        [time x R]
+// 660 MB / ms for the chip; tools/time_few.py: 1024x1024 images, one 0.039 against 1.99 ms, 64: 0.54 against 2.16 ms, 256:
+// 1.96 against 2.21 ms, 320: 2.43 / 2.54, 512: 3.87 / 2.57, 1024: 7.70 against 3.69 ms).  The plan sorts the streams by size
+// and sends the k largest through the passes, k minimising
+//       SQOA_DP_COST * bytes(first k) + max(SQOA_DP_SOLO * bytes(stream k), bytes(rest))        [time x R]
 // i.e. the passes, then the one-workgroup-per-stream kernel bounded by its largest stream or by the chip.
 #ifndef SQOA_DP_COST
-#define SQOA_DP_COST 2.27
+#define SQOA_DP_COST 2.1
 #endif
 #ifndef SQOA_DP_SOLO
 #define SQOA_DP_SOLO (550.0 * 1.25)   // R / r, x 1.25: a stream that shares its CU with other streams is slower than alone
@@ -79,7 +81,7 @@ struct sqoa_hip_plan {
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
-    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // encode: the few large images cut into strips
     size_t st_images_cap = 0, st_strips_cap = 0;
@@ -296,7 +298,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
-    struct dp_image_row { int jid; uint32_t tab_off, nchunks, pad; };   // = sqoa::dp_image / dp_wg (sqoa_decode_wave.hip)
+    struct dp_image_row { int jid; uint32_t tab_off, nchunks, nwgs; };   // = sqoa::dp_image / dp_wg (sqoa_decode_wave.hip)
     struct dp_wg_row { uint32_t img, chunk0; };
     std::vector<dp_image_row> dp_images;
     std::vector<dp_wg_row> dp_wgs;
@@ -349,15 +351,18 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         std::vector<int> sorted(ids_a.size());
         for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
         ids_a.swap(sorted);
+        unsigned long long total_chunks = 0;
+        for (int k = 0; k < n_multi; ++k) total_chunks += sqoa_dp_chunks(jobs[ids_a[k]].src_size);
+        const uint32_t per = sqoa_dp_per_wg(total_chunks, &dp_row_bytes);
+        p->dp.per = per;
         for (int k = 0; k < n_multi; ++k) {
             const int i = ids_a[k];
-            uint32_t nc, per;
-            sqoa_dp_layout(jobs[i].src_size, &nc, &per, &dp_row_bytes);
-            if (dp_rows + nc > 0xffffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
+            const uint32_t nc = sqoa_dp_chunks(jobs[i].src_size), nw = (nc + per - 1) / per;
+            if (dp_wgs.size() + nw > 0x7fffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
             const uint32_t img = (uint32_t)dp_images.size();
-            dp_images.push_back({i, (uint32_t)dp_rows, nc, 0u});
+            dp_images.push_back({i, (uint32_t)dp_rows, nc, nw});
             for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});
-            dp_rows += nc;
+            dp_rows += nw;
         }
     }
     p->n = n;
