@@ -28,8 +28,8 @@
 typedef struct {
     int device;
     sqoa_hip_plan *plan[2];
-    sqoa_hip_job last[2][32]; /* the job table each plan holds: a caller that repeats a call (sqoabench does) skips the upload */
-    int last_n[2];
+    sqoa_hip_job last[2]; /* the job each plan holds: a caller that repeats a call (sqoabench does) skips the upload */
+    int have_last[2];
     unsigned long long d_in, d_out;
     size_t cap_in, cap_out;
 } host_ctx;
@@ -85,45 +85,19 @@ static int grow(host_ctx *c, unsigned long long *d, size_t *cap, size_t need) {
     return 0;
 }
 
-/* n jobs through the thread's plan of the given kind (the plan is created for SQOA_STRIPS_MAX jobs once) */
-static int run_jobs(host_ctx *c, int kind, const sqoa_hip_job *jobs, int n, sqoa_hip_result *res) {
+/* one job through the thread's plan of the given kind */
+static int run_job(host_ctx *c, int kind, const sqoa_hip_job *job, sqoa_hip_result *res) {
     if (!c->plan[kind]) {
-        sqoa_hip_job first[32];
-        memset(first, 0, sizeof first);
-        memcpy(first, jobs, (size_t)n * sizeof *jobs);
-        if (sqoa_hip_plan_create(c->device, kind, first, 32, &c->plan[kind])) { complain("plan"); return -1; }
+        if (sqoa_hip_plan_create(c->device, kind, job, 1, &c->plan[kind])) { complain("plan"); return -1; }
+    } else if (!c->have_last[kind] || memcmp(&c->last[kind], job, sizeof *job)) {
+        c->have_last[kind] = 0;
+        if (sqoa_hip_plan_update(c->plan[kind], job, 1)) { complain("plan update"); return -1; }
     }
-    if (c->last_n[kind] != n || memcmp(c->last[kind], jobs, (size_t)n * sizeof *jobs)) {
-        if (sqoa_hip_plan_update(c->plan[kind], jobs, n)) { c->last_n[kind] = 0; return -1; }
-        memcpy(c->last[kind], jobs, (size_t)n * sizeof *jobs);
-        c->last_n[kind] = n;
-    }
+    c->last[kind] = *job;
+    c->have_last[kind] = 1;
     if (sqoa_hip_plan_launch(c->plan[kind], NULL)) { complain("launch"); return -1; }
-    if (sqoa_hip_plan_results(c->plan[kind], res, n)) { complain("results"); return -1; }
+    if (sqoa_hip_plan_results(c->plan[kind], res, 1)) { complain("results"); return -1; }
     return 0;
-}
-
-/* A large SQOA-native image goes to the GPU as several strip jobs (sqoa_hip.h), i.e. several workgroups: one image is
- * otherwise one workgroup on one compute unit (0.57 ms per Mpixel however idle the other 255 are).  A strip must start at a
- * pixel that differs from its predecessor, so that no run (seqoia.h:544-561) crosses the cut: from each nominal position the
- * cut moves forward to the first such pixel. */
-#define SQOA_STRIPS_MAX 32
-#define SQOA_STRIP_MIN_PX 32768u
-
-static unsigned plan_strips(const unsigned char *px, size_t npx, unsigned stride, size_t *cut /* [SQOA_STRIPS_MAX + 1] */) {
-    unsigned want = (unsigned)(npx / SQOA_STRIP_MIN_PX);
-    if (want > SQOA_STRIPS_MAX) want = SQOA_STRIPS_MAX;
-    unsigned n = 0;
-    cut[n++] = 0;
-    for (unsigned k = 1; k < want; k++) {
-        size_t i = npx * k / want;
-        if (i <= cut[n - 1]) i = cut[n - 1] + 1;
-        while (i < npx && !memcmp(px + i * stride, px + (i - 1) * stride, stride)) i++;
-        if (i >= npx) break; /* the rest of the image is one run */
-        cut[n++] = i;
-    }
-    cut[n] = npx;
-    return n;
 }
 
 void *sqoa_encode(const void *data, const sqoa_desc *desc, int *out_len) {
@@ -136,62 +110,24 @@ void *sqoa_encode(const void *data, const sqoa_desc *desc, int *out_len) {
     if (!c) return NULL;
 
     const unsigned stride = (desc->channels < 3 ? 1u : 3u) + ((desc->channels & 1) ? 0u : 1u);
-    const size_t npx = (size_t)desc->width * desc->height;
-    const size_t in_bytes = npx * stride;
-    size_t cut[SQOA_STRIPS_MAX + 1];
-    unsigned nstrips = 1;
-    cut[0] = 0;
-    cut[1] = npx;
-    if (!desc->qoi_compat && npx >= 2 * (size_t)SQOA_STRIP_MIN_PX) nstrips = plan_strips(data, npx, stride, cut);
-
-    sqoa_hip_job jobs[SQOA_STRIPS_MAX];
-    size_t off[SQOA_STRIPS_MAX + 1];
-    memset(jobs, 0, sizeof jobs);
-    off[0] = 0;
-    for (unsigned k = 0; k < nstrips; k++) {
-        sqoa_desc d = *desc;
-        if (nstrips > 1) { d.width = (unsigned)(cut[k + 1] - cut[k]); d.height = 1; }
-        const size_t bound = sqoa_hip_encode_bound(&d);
-        jobs[k].dst_cap = bound > 0xffffffffu ? 0xffffffffu : (unsigned)bound;
-        jobs[k].desc = d;
-        if (nstrips > 1)
-            jobs[k].reserved = SQOA_HIP_JOB_NOHEADER | (k ? SQOA_HIP_JOB_PREV : 0u) | (k + 1 < nstrips ? SQOA_HIP_JOB_NOEND : 0u);
-        off[k + 1] = off[k] + bound;
-    }
-    /* device buffers: pixels | one worst-case slot per strip | (strips only) the packed stream and its offsets */
-    const size_t blob_at = off[nstrips], offs_at = blob_at + ((off[nstrips] + 255) & ~(size_t)255);
-    if (grow(c, &c->d_in, &c->cap_in, in_bytes) || grow(c, &c->d_out, &c->cap_out, offs_at + 8 * (SQOA_STRIPS_MAX + 1))) return NULL;
-    for (unsigned k = 0; k < nstrips; k++) {
-        jobs[k].src = c->d_in + cut[k] * stride;
-        jobs[k].dst = c->d_out + off[k];
-    }
+    const size_t in_bytes = (size_t)desc->width * desc->height * stride;
+    const size_t bound = sqoa_hip_encode_bound(desc);
+    if (grow(c, &c->d_in, &c->cap_in, in_bytes) || grow(c, &c->d_out, &c->cap_out, bound)) return NULL;
     if (sqoa_hip_memcpy_h2d(c->device, c->d_in, data, in_bytes)) return NULL;
-    sqoa_hip_result res[SQOA_STRIPS_MAX];
-    if (run_jobs(c, SQOA_HIP_ENCODE, jobs, (int)nstrips, res)) return NULL;
-    size_t total = nstrips > 1 ? 15 : 0; /* magic, width, height, channels, colorspace, start byte */
-    for (unsigned k = 0; k < nstrips; k++) {
-        if (res[k].status != SQOA_HIP_ST_OK || res[k].len < 0) return NULL;
-        total += (size_t)res[k].len;
-    }
-    if (total > 0x7fffffffu) return NULL;
-
-    unsigned char *out = malloc(total); /* caller free()s: sqoabench.c:537, seqoia.h:834 */
+    /* one job: a plan that holds a lone large SQOA-native image cuts it into strips on the device (sqoa_strips.hip), i.e.
+     * the whole chip encodes it; the complete stream, header included, ends up at dst */
+    sqoa_hip_job job;
+    memset(&job, 0, sizeof job);
+    job.src = c->d_in;
+    job.dst = c->d_out;
+    job.dst_cap = bound > 0xffffffffu ? 0xffffffffu : (unsigned)bound;
+    job.desc = *desc;
+    sqoa_hip_result res;
+    if (run_job(c, SQOA_HIP_ENCODE, &job, &res) || res.status != SQOA_HIP_ST_OK || res.len <= 0) return NULL;
+    unsigned char *out = malloc((size_t)res.len); /* caller free()s: sqoabench.c:537, seqoia.h:834 */
     if (!out) return NULL;
-    if (nstrips == 1) {
-        if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, total)) { free(out); return NULL; }
-    } else {
-        /* header as seqoia.h:497-514 writes it; the strips' streams, compacted on the device, behind it */
-        static const unsigned char magic[4] = {'S', 'q', 'o', 'a'};
-        memcpy(out, magic, 4);
-        for (int k = 0; k < 4; k++) { out[4 + k] = (unsigned char)(desc->width >> (24 - 8 * k)); out[8 + k] = (unsigned char)(desc->height >> (24 - 8 * k)); }
-        out[12] = (unsigned char)stride;
-        out[13] = desc->colorspace;
-        out[14] = 0x31;
-        unsigned long long packed = 0;
-        if (sqoa_hip_pack(c->plan[SQOA_HIP_ENCODE], c->d_out + blob_at, total - 15, c->d_out + offs_at, &packed, NULL) || packed != total - 15 ||
-            sqoa_hip_memcpy_d2h(c->device, out + 15, c->d_out + blob_at, total - 15)) { free(out); return NULL; }
-    }
-    *out_len = (int)total;
+    if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, (size_t)res.len)) { free(out); return NULL; }
+    *out_len = res.len;
     return out;
 }
 
@@ -234,7 +170,7 @@ void *sqoa_decode(const void *data, int size, sqoa_desc *desc, int channels) {
     job.desc.height = desc->height;
     job.desc.channels = (unsigned char)channels;
     sqoa_hip_result res;
-    if (run_jobs(c, SQOA_HIP_DECODE, &job, 1, &res) || res.status != SQOA_HIP_ST_OK || (size_t)res.len != out_bytes) return NULL;
+    if (run_job(c, SQOA_HIP_DECODE, &job, &res) || res.status != SQOA_HIP_ST_OK || (size_t)res.len != out_bytes) return NULL;
 
     void *out = malloc(out_bytes); /* caller free()s: sqoabench.c:454, :493 */
     if (!out) return NULL;
