@@ -333,6 +333,10 @@ def secondary(sq, torch, dev, headline, k=5):
     for size in (512, 64):
         for qoi in (0, 1):
             row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi))
+    # few large images: the plan cuts them into strips on the device (encode) / decodes them in three chip-wide passes
+    # (DESIGN.md 3.1b, 3.2b); one workgroup per image would be one compute unit's speed (0.57 / 2.0 ms per Mpixel)
+    row("one 3840x2160 RGBA image alone, qoi_compat=0", Uniform(sq, torch, dev, 1, 3840, 2160, 4, "mixed", 0))
+    row("16 x 1024x1024 RGBA, qoi_compat=0", Uniform(sq, torch, dev, 16, 1024, 1024, 4, "mixed", 0))
     return out
 
 

@@ -23,17 +23,26 @@
 
 namespace sqoa {
 
-// Waves per image.  The serial section bounds one image, the instruction volume bounds the chip: 4 waves per image decode
-// large images fastest (1024 x 1 Mpixel: 16.8 ms against 21.5 / 18.6 ms with 2 / 8), 2 waves leave room for twice as many
-// images at once, which is what small images want (4096 icons of 512 x 512: 4.5 ms against 6.1 ms with 4).
+// Waves per image, wave priority and poll interval (round 2, measured on 1024 x 1 Mpixel / 4096 icons of 512 x 512):
+//   * the serial section is the image's critical path: it runs at priority 3, everything else at 0 (16.3 -> 14.5 ms; 3.88 ->
+//     3.63 ms), and with that 8 waves per image beat 4 (13.5 ms; without the priority 8 waves were slower than 4: the wave
+//     in its serial section got an eighth of the issue slots);
+//   * polling a chain word costs scalar instructions, and the scalar pipe -- one per CU -- is what this kernel is short of
+//     (SQ counters at one poll per 64 cycles: 994 SALU + 371 branches per 512-byte chunk, as many as VALU): 16 x 64 cycles
+//     between two looks, 13.4 -> 12.2 ms (4 / 8 / 32: 12.7 / 12.4 / 12.3); polling fast only when the turn is next was
+//     slower than that (13.0);
+//   * small images want twice as many images at once: 2 waves per image (4096 icons: 3.55 ms against 4.3 with 4).
 #ifndef SQOA_QDEC_W
-#define SQOA_QDEC_W 4
+#define SQOA_QDEC_W 8
 #endif
 #ifndef SQOA_QDEC_W_SMALL
 #define SQOA_QDEC_W_SMALL 2
 #endif
 #ifndef SQOA_QDEC_SLEEP
-#define SQOA_QDEC_SLEEP 1
+#define SQOA_QDEC_SLEEP 16
+#endif
+#ifndef SQOA_QDEC_PRIO
+#define SQOA_QDEC_PRIO 3
 #endif
 constexpr int QK_LB = 8;                          // stream bytes per lane
 constexpr int QK_CHUNK = 64 * QK_LB;              // stream bytes per chunk
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
         // ---- the serial section: the pixel entering the chunk (and with it the index as the chunks before left it) ----
         uint32_t pxv = kPxInit;   // seqoia.h:716-719
+        __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
         if (c > 0 && !qk_wait(&s_px[(c - 1) % W], c, pxv, bad)) break;
 #ifdef SQOA_DBG_Q_NOSERIAL
         if (false) {
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         if (!last_chunk) qk_post(&s_px[w], c + 1, pxv, lane);
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- off the serial path: pixels of this chunk's ops; literal ops lane-local, runs by the whole wave ----
         uint32_t P0 = pos_in;
