@@ -42,20 +42,23 @@ constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk 
 constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
 constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 
-// Wait for `slot` to carry `tag`; 0 = it does (val set), 1 = the image was handed over (abort flag), 2 = timed out.  Integer
-// result codes, not bool: a wave-uniform i1 that flows through a merge is kept as a 64-bit lane mask by the compiler
-// (s_cselect_b64 / s_and_b64 vcc, exec / s_cbranch_vccnz instead of s_cmp + s_cbranch_scc), and the scalar pipe is as busy
-// as the vector pipe in this kernel.
-SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, const uint32_t* abort_flag, uint32_t& val) {
-    uint32_t rc = 2;
-    for (uint32_t spin = 0; spin < DEC_SPIN_MAX; ++spin) {
+// Wait for `slot` to carry `tag`; 0 = it does (val set), 1 = the image was handed over (the slot's owner left DEC_ABORT_TAG in
+// it), 2 = timed out.  Integer result codes, not bool: a wave-uniform i1 that flows through a merge is kept as a 64-bit lane
+// mask by the compiler, and the scalar pipe is as busy as the vector pipe in this kernel -- for the same reason a failed poll
+// is as few scalar instructions as it can be: no separate abort flag to look at (a wave that hands the image over, or learns
+// that its predecessor did, writes the abort tag into its OWN three chain words and leaves; every wave waits on its
+// predecessor's words sooner or later, so the news goes round the ring), the spin limit a down-counter.
+constexpr uint32_t DEC_ABORT_TAG = 0xffffffffu;   // (chunk tags are chunk numbers + 1 < 2^32 - 1)
+SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t& val) {
+    uint32_t left = DEC_SPIN_MAX;
+    for (;;) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); rc = 0; break; }
-        // (the abort flag is rare news: looked at on every eighth poll)
-        if ((spin & 7u) == 7u && bcast_first(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) { rc = 1; break; }
+        const uint32_t t = bcast_first((uint32_t)(v >> 32));
+        if (t == tag) { val = bcast_first((uint32_t)v); return 0u; }
+        if (t == DEC_ABORT_TAG) return 1u;
+        if (--left == 0u) return 2u;
         __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
     }
-    return bcast_first(rc);
 }
 
 SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
@@ -209,7 +212,6 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
-    __shared__ uint32_t s_abort;
     __shared__ uint32_t s_path;  // 1 = wave path, 2 = refused
 
     const int lane = lane_id();
@@ -235,9 +237,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     if (MODE >= 2 && chunk_first) seed_st = bcast_first(row->st_in);
     if (MODE == 3 && chunk_first) { seed_pos = bcast_first(row->pos_in); seed_px = bcast_first(row->px_in); }
 
-    if (MODE >= 2 && threadIdx.x == 0) { s_abort = 0; s_path = dp_flags[img]; }   // what pass 1 (or pass 2: SQOA_OP_REF) decided
+    if (MODE >= 2 && threadIdx.x == 0) s_path = dp_flags[img];   // what pass 1 (or pass 2: SQOA_OP_REF) decided
     if ((MODE == 0 || (MODE == 1 && chunk_first == 0)) && threadIdx.x == 0) {
-        s_abort = 0;
         // header (seqoia.h:672-688): written to the result exactly as sqoa_decode fills *desc
         const uint32_t magic = (uint32_t)src[0] << 24 | (uint32_t)src[1] << 16 | (uint32_t)src[2] << 8 | src[3];
         const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         s_path = path;
         if (MODE == 1) dp_flags[img] = path;
     }
-    if (MODE == 1 && chunk_first != 0 && threadIdx.x == 0) { s_abort = 0; s_path = 1; }  // (parsing bytes is harmless whatever the header says)
+    if (MODE == 1 && chunk_first != 0 && threadIdx.x == 0) s_path = 1;  // (parsing bytes is harmless whatever the header says)
     if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
     for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // transition function of a live byte (see header comment)
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const bool early = g_const && MODE != 2;
             if (early && !last_chunk) post(my_parse, c + 1, g0, lane);
             if (c > chunk_first) {
-                const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, &s_abort, st_in);
+                const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in);
                 if (rc) { bad |= rc >> 1; return 0u; }
             }
             if (!early && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
@@ -463,7 +464,6 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const bool ref_lane = (info_or >> 20) & 1u;  // SQOA_OP_REF (what follows it in a lane is discarded with the image)
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
             if (lane == 0) {
-                __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
                 if (MODE) atomicMax(&dp_flags[img], 2u);   // pass 3 leaves the image to the exact decoder
             }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         if (c > chunk_first) {
             // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
             // instructions in order), so it is there when the pixel word's tag is
-            const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, &s_abort, px_in);
+            const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, px_in);
             if (rc) { bad |= rc >> 1; return 0u; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             pos_in = bcast_first((uint32_t)__hip_atomic_load(&s_pos[(c - 1) % W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -590,6 +590,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         for (; go && c < nint; c += W) go = body(std::true_type{}, c);
     }
     for (; go && c < chunk_end; c += W) go = body(std::false_type{}, c);
+    if (!go && lane == 0) {   // handed over (SQOA_OP_REF), or the predecessor was: tell whoever waits on this wave (chain_wait_rc)
+        const unsigned long long gone = (unsigned long long)DEC_ABORT_TAG << 32;
+        __hip_atomic_store(&s_parse[0][w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_parse[1][w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_px[w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if constexpr (MODE == 1 || MODE == 2) {   // the workgroup's chunks composed in stream order -> its row of the table
         __syncthreads();
         if (w == 0) {
