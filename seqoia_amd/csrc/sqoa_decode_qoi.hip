@@ -5,41 +5,49 @@
 // depend on the VALUES of all earlier ones (the slot is a hash of the value), so pixel values cannot be scanned across a
 // chunk the way SQOA's can.  What does parallelise:
 //
-//   * one workgroup of W waves per image, chunk c of 512 stream bytes -> wave c mod W (as in sqoa_decode_wave.hip): staging,
-//     the parser as a scan of transition functions, every lane decoding the ops that start in its 8 bytes, the ops laid out
-//     in stream order as records (transform, INDEX slot, pixel count), and -- between two INDEX ops -- the pixel values as
-//     one segmented scan of the transforms, all BEFORE the chunk knows the pixel or the index it starts from;
-//   * what is serial per image is the walk over the INDEX ops of a chunk: per INDEX op one add, one hash, one compare of
-//     the 64 ops' hashes against the slot (__ballot) and one v_readlane -- "the most recent earlier op of this group whose
-//     pixel hashes to my slot" -- with the index itself as the fall-back;
+//   * one workgroup per image: W - 1 PRODUCER waves and one RESOLVER wave.  Chunk c of 512 stream bytes -> producer c mod
+//     (W - 1), as in sqoa_decode_wave.hip: staging, the parser as a scan of transition functions, every lane decoding the ops
+//     that start in its 8 bytes, the ops laid out in stream order as records (transform, INDEX slot, pixel count), and --
+//     between two INDEX ops -- the pixel values as one segmented scan of the transforms, all without knowing the pixel or the
+//     index the chunk starts from;
+//   * what is serial per image is the walk over the INDEX ops: per INDEX op one add, one hash, one compare of the 64 ops'
+//     hashes against the slot (__ballot) and one v_readlane -- "the most recent earlier op of this group whose pixel hashes
+//     to my slot" -- with the index itself as the fall-back.  ONE wave does that for every chunk of the image, back to back,
+//     at raised priority: the running pixel stays in a register, there is no hand-over from wave to wave per chunk (which
+//     cost a post, a poll and a wake-up on the image's critical path 5 000 times per Mpixel image);
 //   * the index lives in LDS, ONE copy per image, as 64 x {value, stamp}: "index[hash(px)] = px" for 64 ops at once is one
 //     ds_max_u64 of (stream-order stamp << 32 | value) per op -- the last writer of a slot wins exactly as the
-//     reference's in-order stores do -- and the waves hand the serial section to each other through the same tagged LDS
-//     words as the SQOA decoder; nothing is copied between waves;
-//   * pixel stores and run expansion happen after the chunk has handed on, off the serial path.
+//     reference's in-order stores do;
+//   * the producer picks its records up again when the resolver is done with them -- by then it has parsed and decoded its
+//     next chunk -- and does the pixel stores and run expansion, off the serial path.
 #include <type_traits>
 
 #include "sqoa_decode_parts.h"
 
 namespace sqoa {
 
-// Waves per image, wave priority and poll interval (round 2, measured on 1024 x 1 Mpixel / 4096 icons of 512 x 512):
-//   * the serial section is the image's critical path: it runs at priority 3, everything else at 0 (16.3 -> 14.5 ms; 3.88 ->
-//     3.63 ms), and with that 8 waves per image beat 4 (13.5 ms; without the priority 8 waves were slower than 4: the wave
-//     in its serial section got an eighth of the issue slots);
-//   * polling a chain word costs scalar instructions, and the scalar pipe -- one per CU -- is what this kernel is short of
-//     (SQ counters at one poll per 64 cycles: 994 SALU + 371 branches per 512-byte chunk, as many as VALU): 16 x 64 cycles
-//     between two looks, 13.4 -> 12.2 ms (4 / 8 / 32: 12.7 / 12.4 / 12.3); polling fast only when the turn is next was
-//     slower than that (13.0);
-//   * small images want twice as many images at once: 2 waves per image (4096 icons: 3.55 ms against 4.3 with 4).
+#ifdef SQOA_ASM_MARK  // phase markers as comments in the assembly (tools/asm_cost.py by region)
+#define QP(k) asm volatile("; SQOA_QPHASE " #k)
+#else
+#define QP(k) do { } while (0)
+#endif
+
+// Waves per image (one of them the resolver), wave priority and poll intervals.  History on 1024 x 1 Mpixel / 4096 icons of
+// 512 x 512, every wave both producing and resolving its own chunks: the serial section at priority 3 16.3 -> 14.5 ms (3.88 ->
+// 3.63 ms), with that 8 waves per image instead of 4 13.5 ms; polling a chain word costs scalar instructions and the scalar pipe
+// -- one per CU -- was saturated (994 SALU + 371 branches per 512-byte chunk, as many as VALU): 16 x 64 cycles between two
+// looks 12.2 ms.  Small images want more images at once: fewer waves per image.
 #ifndef SQOA_QDEC_W
 #define SQOA_QDEC_W 8
 #endif
 #ifndef SQOA_QDEC_W_SMALL
-#define SQOA_QDEC_W_SMALL 2
+#define SQOA_QDEC_W_SMALL 4
 #endif
 #ifndef SQOA_QDEC_SLEEP
-#define SQOA_QDEC_SLEEP 16
+#define SQOA_QDEC_SLEEP 16      // producers: x 64 cycles between two looks at a chain word
+#endif
+#ifndef SQOA_QDEC_RSLEEP
+#define SQOA_QDEC_RSLEEP 1      // the resolver, when the next chunk's records are not there yet
 #endif
 #ifndef SQOA_QDEC_PRIO
 #define SQOA_QDEC_PRIO 3
@@ -64,11 +72,12 @@ SQOA_DEV Xf qk_seg_step(Xf T, uint32_t& hf) {
     return R;
 }
 
+template <int SLEEP = SQOA_QDEC_SLEEP>
 SQOA_DEV bool qk_wait(unsigned long long* slot, uint32_t tag, uint32_t& val, uint32_t& bad) {
     for (uint32_t spin = 0; spin < QK_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
-        __builtin_amdgcn_s_sleep(SQOA_QDEC_SLEEP);
+        __builtin_amdgcn_s_sleep(SLEEP);
     }
     bad = 1;
     return false;
@@ -89,16 +98,23 @@ template <int W>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_qoi_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                                                    const int* __restrict__ job_ids,
                                                                                                    sqoa_hip_result* __restrict__ results) {
-    __shared__ uint32_t s_bytes[W][QK_LDS_DW];
+    constexpr int P = W - 1;                       // producer waves; wave 0 is the resolver
+    __shared__ uint32_t s_bytes[P][QK_LDS_DW];
     __shared__ uint32_t s_ftab[256];               // byte -> low half of its parser transition function
-    // per op of the wave's chunk, in stream order: transform value bytes (later: the transform scanned over its segment,
-    // later still: the op's pixel), and 1 = INDEX | absolute-channel code (2 = rgb, 4 = rgba) | slot << 3 | pixel count << 9
-    __shared__ uint32_t s_recv[W][QK_CHUNK];
-    __shared__ uint16_t s_recm[W][QK_CHUNK];
+    // op byte -> {length | 1 << 3 | record word << 16, absolute-channel mask, relative value bytes 0 and 2, LUMA nibble mask |
+    // relative value byte 1}: the op decode of seqoia.h:740-775 (qoi_compat) as one look-up and mask arithmetic (the if / else
+    // chain it replaces was 85 VALU + 36 scalar instructions per op slot); entry 256 = "no op" for lanes that have run out
+    __shared__ __attribute__((aligned(16))) u32x4 s_qtab[257];
+    // per op of the producer's chunk, in stream order: transform value bytes (later: the transform scanned over its segment,
+    // later still: the op's pixel), and 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixel count << 9
+    __shared__ uint32_t s_recv[P][QK_CHUNK];
+    __shared__ uint16_t s_recm[P][QK_CHUNK];
     __shared__ unsigned long long s_tab[64];       // the colour index (seqoia.h:712, :785-787): stamp << 32 | value
-    __shared__ unsigned long long s_parse[2][W];
-    __shared__ unsigned long long s_pos[W];
-    __shared__ unsigned long long s_px[W];
+    __shared__ unsigned long long s_parse[2][P];
+    __shared__ unsigned long long s_pos[P];
+    __shared__ unsigned long long s_ready[P];      // producer -> resolver: chunk + 1 << 32 | ops in the chunk | 1 << 31: nothing to resolve (past the image)
+    __shared__ unsigned long long s_done[P];       // resolver -> producer: chunk + 1 << 32 | the pixel the chunk ends with
+    __shared__ unsigned long long s_smask[64];     // resolver scratch: per index slot, the lanes of the group whose pixel hashes to it
     __shared__ uint32_t s_go;
 
     const int lane = lane_id();
@@ -119,13 +135,24 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         s_go = go;
     }
-    if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
+    if (lane == 0 && w < P) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_ready[w] = 0; s_done[w] = 0; }
     if (threadIdx.x < 64) s_tab[threadIdx.x] = 0;   // seqoia.h:712
     for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // op lengths: fe 4, ff 5, 10xxxxxx 2, all others 1
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
         s_ftab[b0] = opn | opn << 8 | 0x02000000u;
+        const bool is_rgb = b0 == 0xfeu, is_rgba = b0 == 0xffu, is_idx = b0 < 0x40u, is_diff = (b0 & 0xc0u) == 0x40u, is_luma = (b0 & 0xc0u) == 0x80u;
+        const uint32_t cnt = (is_rgb || is_rgba || is_idx || is_diff || is_luma) ? 1u : (b0 & 0x3fu) + 1u;   // seqoia.h:773-775 (0xfd / 0xfc: runs of 62 / 61 here)
+        const uint32_t vg = (b0 & 0x3fu) - 32u;
+        u32x4 e;
+        e.x = len | 1u << 3 | ((is_idx ? (1u | b0 << 3) : 0u) | cnt << 9) << 16;
+        e.y = is_rgb ? 0x00ffffffu : is_rgba ? 0xffffffffu : 0u;
+        e.z = is_diff ? (((((b0 >> 4) & 3u) - 2u) & 0xffu) | (((b0 & 3u) - 2u) & 0xffu) << 16)      // seqoia.h:756-760
+                      : is_luma ? (((vg - 8u) & 0xffu) | ((vg - 8u) & 0xffu) << 16) : 0u;          // seqoia.h:761-769
+        e.w = is_diff ? ((((b0 >> 2) & 3u) - 2u) & 0xffu) << 8 : is_luma ? ((vg & 0xffu) << 8 | 0x000f000fu) : 0u;
+        s_qtab[b0] = e;
     }
+    if (threadIdx.x == 0) { u32x4 z = {0u, 0u, 0u, 0u}; s_qtab[256] = z; }
     __syncthreads();
     if (!s_go) return;
     __syncthreads();
@@ -148,17 +175,89 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t nchunks = area ? (area + QK_CHUNK - 1) / QK_CHUNK : 1;
     uint32_t bad = 0;
 
-    uint32_t* lds = s_bytes[w];
-    uint32_t* recv = s_recv[w];
-    uint16_t* recm = s_recm[w];
+    // ================= the resolver: every chunk's serial section, in stream order ==========================================
+    if (w == 0) {
+        __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
+        const unsigned long long bit = 1ull << lane, lt_mask = bit - 1ull;
+        uint32_t pxv = kPxInit;   // seqoia.h:716-719
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            uint32_t hopen = pxv;   // the pixel the segment that is open at a group's first op started from: the one entering the chunk, or an INDEX op's
+            const uint32_t p = c % (uint32_t)P;
+            uint32_t info = 0;
+            if (!qk_wait<SQOA_QDEC_RSLEEP>(&s_ready[p], c + 1, info, bad)) break;
+            const uint32_t T = info & 0xffffu;
+            uint32_t* recv = s_recv[p];
+            uint16_t* recm = s_recm[p];
+#ifdef SQOA_DBG_Q_NOSERIAL
+            if (false) {
+#else
+            if (!(info >> 31)) {
+#endif
+                for (uint32_t gb = 0; gb < T; gb += 64) {
+                    const uint32_t ng = T - gb < 64u ? T - gb : 64u;
+                    const bool live = (uint32_t)lane < ng;
+                    const uint32_t m = live ? recm[gb + lane] : 0u;
+                    const uint32_t Sv = live ? recv[gb + lane] : 0u;
+                    const uint32_t nabs = (m & 4u) ? 0u : (m & 2u) ? 0xff000000u : 0xffffffffu;   // channels still relative to the segment's start
+                    const bool isx = (m & 1u) != 0u;
+                    const uint32_t slot = (m >> 3) & 63u;
+                    // the INDEX op at or below me that my segment starts at (none: it starts from the pixel entering the group)
+                    const unsigned long long idxmask = __ballot(isx);
+                    const unsigned long long below = idxmask & (lt_mask | bit);
+                    const uint32_t head = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                    const uint32_t from_in = below ? 0u : ~0u;
+                    // All the group's INDEX ops at once, as a fixed point (seqoia.h:753-755 for each of them): an INDEX op's pixel
+                    // X is "the most recent earlier op whose pixel hashes to my slot, else the index as the groups before left
+                    // it"; the pixels of the ops behind it follow from X.  Start from the index, recompute until nothing
+                    // changes: every round settles at least the first INDEX op that was still wrong (the ops in front of it are
+                    // final), in practice one round finds nothing to change -- where one INDEX op after the other cost a
+                    // VALU -> SALU -> VALU round trip each.
+                    const uint32_t tabv = isx ? (uint32_t)__hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                    uint32_t X = tabv, val = 0, hv = 0;
+                    for (uint32_t round = 0; round <= ng; ++round) {
+                        const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(head << 2), (int)X);
+                        val = add8(((hx & ~from_in) | (hopen & from_in)) & nabs, Sv);
+                        hv = qoi_hash(val);
+                        if (idxmask == 0ull) break;                      // no INDEX op in the group: nothing to look up
+                        s_smask[lane] = 0ull;                            // per slot: the lanes whose pixel hashes to it
+                        if (live) __hip_atomic_fetch_or(&s_smask[hv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned long long earlier = __hip_atomic_load(&s_smask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & lt_mask;
+                        const uint32_t last = earlier ? 63u - (uint32_t)__builtin_clzll(earlier) : 0u;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)val);
+                        const uint32_t Xn = earlier ? got : tabv;
+                        const bool changed = isx && Xn != X;
+                        X = Xn;
+                        if (__ballot(changed) == 0ull) break;
+                    }
+                    pxv = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(ng - 1u));
+                    if (idxmask) hopen = (uint32_t)__builtin_amdgcn_readlane((int)X, 63 - __builtin_clzll(idxmask));
+                    // seqoia.h:785-787 for the whole group: the last writer of a slot wins
+                    if (live) {
+                        __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        recv[gb + lane] = val;   // for the producer's stores
+                    }
+                }
+            }
+            qk_post(&s_done[p], c + 1, pxv, lane);
+        }
+        if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+        return;
+    }
+
+    // ================= the producers =======================================================================================
+    const uint32_t p = (uint32_t)w - 1u;
+    uint32_t* lds = s_bytes[p];
+    uint32_t* recv = s_recv[p];
+    uint16_t* recm = s_recm[p];
     uint32_t stg[QK_NLD];
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[QK_NLD]) {
         const uint32_t d0 = (p0 + c * QK_CHUNK) >> 2;
         if ((d0 + QK_LDS_DW) * 4u <= size) {
-            gcptr32 p = (gcptr32)src + d0;
+            gcptr32 q = (gcptr32)src + d0;
 #pragma unroll
-            for (int k = 0; k < QK_NLD - 1; ++k) r[k] = p[lane + 64 * k];
-            r[QK_NLD - 1] = p[64 * (QK_NLD - 1) + (lane & 7)];
+            for (int k = 0; k < QK_NLD - 1; ++k) r[k] = q[lane + 64 * k];
+            r[QK_NLD - 1] = q[64 * (QK_NLD - 1) + (lane & 7)];
         } else {
 #pragma unroll
             for (int k = 0; k < QK_NLD; ++k) {
@@ -168,30 +267,70 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
     };
 
-    auto put = [&](uint32_t P, uint32_t v) {   // one pixel (seqoia.h:790-805, colour)
-        if (dw_out) ((gptr32)out)[P] = v;
+    auto put = [&](uint32_t P_, uint32_t v) {   // one pixel (seqoia.h:790-805, colour)
+        if (dw_out) ((gptr32)out)[P_] = v;
         else {
-            gptr8 o = out + (size_t)P * (unsigned)oc;
+            gptr8 o = out + (size_t)P_ * (unsigned)oc;
             o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
             if (oc == 4) o[3] = (uint8_t)(v >> 24);
         }
     };
 
-    uint32_t c = w;
+    // The pixels of the chunk whose records sit in my buffer, once the resolver is done with them: literal ops lane-local,
+    // runs by the whole wave; the last chunk repeats the final pixel to the end of the image (seqoia.h:726).
+    uint32_t held = ~0u, held_T = 0, held_pos = 0, held_out = 0;   // the chunk in my buffer, its ops, its first pixel, the pixel behind it
+    auto flush_held = [&]() -> bool {
+        if (held == ~0u) return true;
+        uint32_t pxv = 0;
+        if (!qk_wait(&s_done[p], held + 1, pxv, bad)) return false;
+        uint32_t P0 = held_pos;
+#ifdef SQOA_DBG_Q_NOOUT
+        P0 = N;
+#endif
+        for (uint32_t gb = 0; gb < held_T && P0 < N; gb += 64) {
+            const bool live = gb + (uint32_t)lane < held_T;
+            const uint32_t cnt = live ? (uint32_t)recm[gb + lane] >> 9 : 0u;
+            const uint32_t v = live ? recv[gb + lane] : 0u;
+            const uint32_t pinc = wave_incl_scan(cnt);
+            const uint32_t Pp = P0 + pinc - cnt;
+            if (cnt >= 1u && cnt <= 2u && Pp < N) put(Pp, v);
+            if (cnt == 2u && Pp + 1u < N) put(Pp + 1u, v);
+            unsigned long long runs = __ballot(cnt > 2u && Pp < N);
+            while (runs) {  // seqoia.h:723-725
+                const int l = __builtin_ctzll(runs);
+                runs &= runs - 1ull;
+                const uint32_t rp = bcast_lane(Pp, l), rvv = bcast_lane(v, l);
+                uint32_t rc = bcast_lane(cnt, l);
+                if (rp + rc > N) rc = N - rp;
+                for (uint32_t k = lane; k < rc; k += 64) put(rp + k, rvv);
+            }
+            P0 += bcast_lane(pinc, 63);
+        }
+        if (held == nchunks - 1) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
+            for (uint32_t k = held_out + lane; k < N; k += 64) put(k, pxv);
+            if (lane == 0) res->len = (int)(N * (uint32_t)oc);
+        }
+        held = ~0u;
+        return true;
+    };
+
+    uint32_t c = p;
     if (c < nchunks) load_chunk(c, stg);
-    for (; c < nchunks; c += W) {
+    for (; c < nchunks; c += P) {
         const bool last_chunk = c == nchunks - 1;
         // ---- stage the chunk's bytes (+ look-ahead); prefetch the wave's next chunk ----
+        QP(0);
 #pragma unroll
         for (int k = 0; k < QK_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
         if (lane < QK_LDS_DW - 64 * (QK_NLD - 1)) lds[lane + 64 * (QK_NLD - 1)] = stg[QK_NLD - 1];
-        if (c + W < nchunks) load_chunk(c + W, stg);
+        if (c + P < nchunks) load_chunk(c + P, stg);
         const uint32_t gs = p0 + c * QK_CHUNK;
         const uint32_t my0 = gs + QK_LB * lane;
         const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)QK_LB ? (uint32_t)QK_LB : chunks_len - my0);
         const uint32_t loff = (gs & 3u) + QK_LB * lane;
 
         // ---- parse: the state in front of every lane's first byte (A, D1..D4; X past the chunk area) ----
+        QP(1);
         const unsigned long long own = lds_read8(lds, loff);
         Fn F{ID_LO, ID_HI};
 #pragma unroll
@@ -205,160 +344,108 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
         const uint32_t g0 = G.lo & 0xffu;
         const bool g_const = G.lo == g0 * 0x01010101u && (G.hi & 0xffffu) == g0 * 0x0101u;
-        unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
+        // (an exit state that does not depend on the entry state is posted before the entry state is known; the two-deep slots are
+        // safe because the position chain below holds a producer back: it cannot finish chunk c + P before chunk c + 1 was entered)
+        unsigned long long* my_parse = &s_parse[(c / P) & 1][p];
         if (g_const && !last_chunk) qk_post(my_parse, c + 1, g0, lane);
         uint32_t st_in = ST_A;
-        if (c > 0 && !qk_wait(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in, bad)) break;
+        if (c > 0 && !qk_wait(&s_parse[((c - 1) / P) & 1][(c - 1) % P], c, st_in, bad)) break;
         if (!g_const && !last_chunk) qk_post(my_parse, c + 1, apply(G, st_in), lane);
         const uint32_t lst = apply(Fx, st_in);
 
         // ---- walk: my ops, in order (seqoia.h:740-775 with qoi_compat) ----
+        QP(2);
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)QK_LB : 0u);
-        uint32_t rv[QK_LB], rm[QK_LB];
+        // Between two INDEX ops pixel values do not depend on the index: every op's record is its pixel RELATIVE to the INDEX op
+        // (or the chunk start) its segment begins at.  Inside the lane the ops' transforms are composed as they are decoded; what
+        // the lanes below contribute comes from one segmented scan over the lanes' totals further down.
+        uint32_t rv[QK_LB], rm[QK_LB];   // record value; record word: 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixels << 9
         uint32_t nops = 0, iters = QK_LB, cl = 0;
+        Xf Tl{0u, 0u};                   // my ops so far, since my last INDEX op (or my first byte)
+        uint32_t closed = 0, seen = 0;   // bit i: an INDEX op of mine sits at or in front of my op i (its record is final as it is)
+        const uint32_t lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + loff;
+        const uint32_t qtab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u32x4*)s_qtab;
+        typedef const __attribute__((address_space(3))) uint32_t* lcptr32;
+        typedef const __attribute__((address_space(3))) u32x4* lcptr128;
 #pragma unroll
         for (int i = 0; i < QK_LB; ++i) {
-            const bool act = pos < nlive;
-            if (__ballot(act) == 0ull) { iters = i; break; }
-            const unsigned long long q = lds_read8(lds, loff + (pos < (uint32_t)QK_LB ? pos : (uint32_t)QK_LB));
-            const uint32_t b0 = (uint32_t)q & 0xffu, b1 = ((uint32_t)q >> 8) & 0xffu;
-            uint32_t v = 0, m = 0, cnt = 1, len = 1;
-            if (b0 >= 0xfeu) {                       // seqoia.h:740-752
-                v = (uint32_t)(q >> 8) & (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu);
-                m = b0 == 0xffu ? 4u : 2u;
-                len = b0 - 0xfau;
-            } else if (b0 < 0x40u) {                 // seqoia.h:753-755
-                m = 1u | b0 << 3;
-            } else if (b0 < 0x80u) {                 // seqoia.h:756-760
-                v = ((((b0 >> 4) & 3u) - 2u) & 0xffu) | ((((b0 >> 2) & 3u) - 2u) & 0xffu) << 8 | (((b0 & 3u) - 2u) & 0xffu) << 16;
-            } else if (b0 < 0xc0u) {                 // seqoia.h:761-769
-                const uint32_t vg = (b0 & 0x3fu) - 32u;
-                v = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
-                len = 2;
-            } else cnt = (b0 & 0x3fu) + 1u;          // seqoia.h:773-775 (0xfd is a run of 62 here, 0xfc one of 61)
-            rv[i] = v;
-            rm[i] = act ? (m | cnt << 9) : 0u;
-            nops += act ? 1u : 0u;
-            cl += act ? cnt : 0u;
-            pos += act ? len : 0u;
+            if (__ballot(pos < nlive) == 0ull) { iters = i; break; }
+            const uint32_t m_act = sra31(pos - nlive);                      // ~0 while I still have an op (pos < nlive <= 8)
+            const uint32_t a = lane_addr + ((pos & m_act) | ((uint32_t)QK_LB & ~m_act));
+            lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+            const uint32_t idx = (((lo & 0xffu) - 256u) & m_act) + 256u;    // lanes out of ops decode the "no op" entry
+            const u32x4 e = *(lcptr128)(uintptr_t)(qtab_addr + idx * 16u);
+            const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;     // LUMA: dr_dg, db_dg (seqoia.h:765-768)
+            const uint32_t rel = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u);
+            const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8);                     // RGB / RGBA: the bytes behind the op byte
+            const uint32_t v = (rel & ~e.y) | (base & e.y);
+            const uint32_t xm = sra31(e.x << 15);                                           // ~0: an INDEX op (bit 16 of the table word)
+            Tl.v = add8(Tl.v & ~e.y, v) & ~xm;                                              // (the "no op" entry composes the identity)
+            Tl.abs = (Tl.abs | e.y) & ~xm;
+            seen |= xm;
+            closed |= seen & (1u << i);
+            rv[i] = Tl.v;
+            rm[i] = (e.x >> 16) | ((Tl.abs >> 22) & 6u);
+            nops += (e.x >> 3) & 1u;
+            cl += e.x >> 25;
+            pos += e.x & 7u;
         }
 
         iters = bcast_first(iters);  // wave-uniform by construction: scalar slot tests below
-        // ---- records in stream order ----
         const uint32_t oinc = wave_incl_scan(nops);
         const uint32_t T = bcast_lane(oinc, 63);
         const uint32_t obase = oinc - nops;
         const uint32_t ctot = bcast_lane(wave_incl_scan(cl), 63);   // pixels this chunk's ops produce
-#pragma unroll
-        for (int i = 0; i < QK_LB; ++i) {
-            if ((uint32_t)i >= iters) break;
-            if (rm[i] >> 9) { recv[obase + i] = rv[i]; recm[obase + i] = (uint16_t)rm[i]; }
-        }
-        // ---- between two INDEX ops pixel values do not depend on the index: one segmented scan of the transforms per 64
-        //      ops; a segment starts AT an INDEX op (whose own transform is the identity) and at the group's first op ----
-#ifndef SQOA_DBG_Q_NOSEG
-        for (uint32_t gb = 0; gb < T; gb += 64) {
-            const bool live = gb + (uint32_t)lane < T;
-            const uint32_t m = live ? recm[gb + lane] : 0u;
-            const bool isx = m & 1u;
-            Xf S{(live && !isx) ? recv[gb + lane] : 0u, (m & 2u) ? 0x00ffffffu : (m & 4u) ? 0xffffffffu : 0u};
-            uint32_t hf = (isx || lane == 0) ? ~0u : 0u;
+
+        // ---- my buffer still holds my previous chunk: its pixels go out now (the resolver has long been through it) ----
+        QP(3);
+        if (!flush_held()) break;
+
+        // ---- what enters my lane: the lanes below me back to the nearest one that holds an INDEX op (its ops behind that op) ----
+        QP(4);
+        Xf E;
+        {
+            Xf S = Tl;
+            uint32_t hf = closed ? ~0u : 0u;
             S = qk_seg_step<DPP_ROW_SHR + 1, 0xf>(S, hf);
             S = qk_seg_step<DPP_ROW_SHR + 2, 0xf>(S, hf);
             S = qk_seg_step<DPP_ROW_SHR + 4, 0xf>(S, hf);
             S = qk_seg_step<DPP_ROW_SHR + 8, 0xf>(S, hf);
             S = qk_seg_step<DPP_ROW_BCAST15, 0xa>(S, hf);
             S = qk_seg_step<DPP_ROW_BCAST31, 0xc>(S, hf);
-            if (live) {
-                recv[gb + lane] = S.v;
-                recm[gb + lane] = (uint16_t)((m & ~6u) | (S.abs == 0xffffffffu ? 4u : S.abs ? 2u : 0u));
+            E = Xf{shift_up1(S.v, 0u), shift_up1(S.abs, 0u)};
+        }
+        // ---- records in stream order: my ops in front of my first INDEX op continue the segment that enters the lane ----
+        QP(5);
+#pragma unroll
+        for (int i = 0; i < QK_LB; ++i) {
+            if ((uint32_t)i >= iters) break;
+            const uint32_t open = ((closed >> i) & 1u) - 1u;                       // ~0: no INDEX op of mine at or in front of op i
+            const uint32_t m = rm[i];
+            const uint32_t ab = (m & 4u) ? 0xffffffffu : (m & 2u) ? 0x00ffffffu : 0u;
+            const uint32_t sv = add8(E.v & open & ~ab, rv[i]);
+            const uint32_t sa = (E.abs & open) | ab;
+            if (m >> 9) {
+                recv[obase + i] = sv;
+                recm[obase + i] = (uint16_t)((m & ~6u) | ((sa >> 22) & 6u));
             }
         }
-#endif
 
         // ---- pixel position: a plain sum, handed on at once ----
+        QP(6);
         uint32_t pos_in = 0;
-        if (c > 0 && !qk_wait(&s_pos[(c - 1) % W], c, pos_in, bad)) break;
+        if (c > 0 && !qk_wait(&s_pos[(c - 1) % P], c, pos_in, bad)) break;
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-        if (!last_chunk) qk_post(&s_pos[w], c + 1, pos_out, lane);
+        if (!last_chunk) qk_post(&s_pos[p], c + 1, pos_out, lane);
 
-        // ---- the serial section: the pixel entering the chunk (and with it the index as the chunks before left it) ----
-        uint32_t pxv = kPxInit;   // seqoia.h:716-719
-        __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
-        if (c > 0 && !qk_wait(&s_px[(c - 1) % W], c, pxv, bad)) break;
-#ifdef SQOA_DBG_Q_NOSERIAL
-        if (false) {
-#else
-        if (pos_in < N) {
-#endif
-            for (uint32_t gb = 0; gb < T; gb += 64) {
-                const uint32_t ng = T - gb < 64u ? T - gb : 64u;
-                const bool live = (uint32_t)lane < ng;
-                const uint32_t m = live ? recm[gb + lane] : 0u;
-                const uint32_t Sv = live ? recv[gb + lane] : 0u;
-                const uint32_t nabs = (m & 2u) ? 0xff000000u : (m & 4u) ? 0u : 0xffffffffu;   // channels still relative to the segment's start
-                unsigned long long idxmask = __ballot((m & 1u) != 0u);
-                uint32_t vres = 0, hres = ~0u;   // pixel and index slot of every op resolved so far (unresolved: no slot)
-                uint32_t s0 = 0;
-                for (;;) {
-                    const uint32_t j = idxmask ? (uint32_t)__builtin_ctzll(idxmask) : ng;   // the next INDEX op, or the end of the group
-                    // ops [s0, j): their segment starts from pxv
-                    const uint32_t val = add8(pxv & nabs, Sv);
-                    const uint32_t hv = qoi_hash(val);
-                    const unsigned long long seg = (j >= 64u ? ~0ull : (1ull << j) - 1ull) & ~((1ull << s0) - 1ull);
-                    vres = select_mask(vres, val, seg);
-                    hres = select_mask(hres, hv, seg);
-                    if (j >= ng) break;
-                    // seqoia.h:753-755: the slot as the ops so far left it -- the most recent op of this group whose pixel hashes
-                    // to it, else the index in LDS (ops of earlier groups and chunks)
-                    const uint32_t slot = ((uint32_t)__builtin_amdgcn_readlane((int)m, (int)j) >> 3) & 63u;
-                    const unsigned long long cand = __ballot(hres == slot);
-                    if (cand) pxv = (uint32_t)__builtin_amdgcn_readlane((int)vres, 63 - __builtin_clzll(cand));
-                    else pxv = bcast_first((uint32_t)__hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    idxmask &= idxmask - 1ull;
-                    s0 = j;
-                }
-                pxv = (uint32_t)__builtin_amdgcn_readlane((int)vres, (int)(ng - 1u));
-                // seqoia.h:785-787 for the whole group: the last writer of a slot wins
-                if (live) {
-                    __hip_atomic_fetch_max(&s_tab[hres & 63u], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | vres, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    recv[gb + lane] = vres;   // for the stores below
-                }
-            }
-        }
-        if (!last_chunk) qk_post(&s_px[w], c + 1, pxv, lane);
-        __builtin_amdgcn_s_setprio(0);
-
-        // ---- off the serial path: pixels of this chunk's ops; literal ops lane-local, runs by the whole wave ----
-        uint32_t P0 = pos_in;
-#ifdef SQOA_DBG_Q_NOOUT
-        P0 = N;
-#endif
-        for (uint32_t gb = 0; gb < T && P0 < N; gb += 64) {
-            const bool live = gb + (uint32_t)lane < T;
-            const uint32_t cnt = live ? (uint32_t)recm[gb + lane] >> 9 : 0u;
-            const uint32_t v = live ? recv[gb + lane] : 0u;
-            const uint32_t pinc = wave_incl_scan(cnt);
-            const uint32_t P = P0 + pinc - cnt;
-            if (cnt >= 1u && cnt <= 2u && P < N) put(P, v);
-            if (cnt == 2u && P + 1u < N) put(P + 1u, v);
-            unsigned long long runs = __ballot(cnt > 2u && P < N);
-            while (runs) {  // seqoia.h:723-725
-                const int l = __builtin_ctzll(runs);
-                runs &= runs - 1ull;
-                const uint32_t rp = bcast_lane(P, l), rvv = bcast_lane(v, l);
-                uint32_t rc = bcast_lane(cnt, l);
-                if (rp + rc > N) rc = N - rp;
-                for (uint32_t k = lane; k < rc; k += 64) put(rp + k, rvv);
-            }
-            P0 += bcast_lane(pinc, 63);
-        }
-        if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
-            for (uint32_t k = pos_out + lane; k < N; k += 64) put(k, pxv);
-            if (lane == 0) res->len = (int)(N * (uint32_t)oc);
-        }
+        // ---- over to the resolver (release: the records are in LDS when the tag is) ----
+        QP(7);
+        qk_post(&s_ready[p], c + 1, T | (pos_in < N ? 0u : 1u << 31), lane);
+        held = c; held_T = T; held_pos = pos_in; held_out = pos_out;
     }
+    if (!bad) flush_held();
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 }
 
