@@ -180,11 +180,19 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
         const unsigned long long bit = 1ull << lane, lt_mask = bit - 1ull;
         uint32_t pxv = kPxInit;   // seqoia.h:716-719
+#ifdef SQOA_QTRACE  // diagnostic builds: where the resolver's time goes, written over the image's first pixels
+        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#define RPH(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define RPH(k) do { } while (0)
+#endif
         for (uint32_t c = 0; c < nchunks; ++c) {
             uint32_t hopen = pxv;   // the pixel the segment that is open at a group's first op started from: the one entering the chunk, or an INDEX op's
             const uint32_t p = c % (uint32_t)P;
             uint32_t info = 0;
+            RPH(0);
             if (!qk_wait<SQOA_QDEC_RSLEEP>(&s_ready[p], c + 1, info, bad)) break;
+            RPH(1);
             const uint32_t T = info & 0xffffu;
             uint32_t* recv = s_recv[p];
             uint16_t* recm = s_recm[p];
@@ -212,8 +220,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // changes: every round settles at least the first INDEX op that was still wrong (the ops in front of it are
                     // final), in practice one round finds nothing to change -- where one INDEX op after the other cost a
                     // VALU -> SALU -> VALU round trip each.
+                    RPH(2);
                     const uint32_t tabv = isx ? (uint32_t)__hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
                     uint32_t X = tabv, val = 0, hv = 0;
+                    RPH(3);
                     for (uint32_t round = 0; round <= ng; ++round) {
                         const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(head << 2), (int)X);
                         val = add8(((hx & ~from_in) | (hopen & from_in)) & nabs, Sv);
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         X = Xn;
                         if (__ballot(changed) == 0ull) break;
                     }
+                    RPH(4);
                     pxv = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(ng - 1u));
                     if (idxmask) hopen = (uint32_t)__builtin_amdgcn_readlane((int)X, 63 - __builtin_clzll(idxmask));
                     // seqoia.h:785-787 for the whole group: the last writer of a slot wins
@@ -239,8 +250,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     }
                 }
             }
+            RPH(5);
             qk_post(&s_done[p], c + 1, pxv, lane);
         }
+#ifdef SQOA_QTRACE
+        if (lane == 0) { unsigned long long* tr = (unsigned long long*)job.dst; for (int k = 0; k < 8; ++k) tr[k] = ph[k]; tr[6] = nchunks; }
+#endif
         if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
         return;
     }
