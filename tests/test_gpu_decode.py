@@ -592,3 +592,42 @@ def test_mono_streams_all_channel_args(sq, orc):
             assert res["status"][i] == 0 and res["len"][i] == len(want), (arg, i)
             assert bytes(outs[i].cpu().numpy()) == want.tobytes(), (arg, i)
         dec.close()
+
+
+def test_many_short_qoi_streams_take_the_small_workgroup_shape(sq, orc):
+    """More than 2048 short streams in one plan: the QOI-compat decoder runs with fewer waves per image (more images at once;
+    decode_qoi_kernel<SQOA_QDEC_W_SMALL>).  Random-body streams (INDEX on an empty table, runs, every op length) and encoder
+    output, RGB and RGBA, to 3 and 4 channels; every stream against the reference."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(909)
+    w, h = 24, 20
+    base = []
+    for k in range(48):
+        ch = (3, 4)[k & 1]
+        if k % 3 == 0:   # random bytes behind a valid QOI-compat header (1..3 chunks of 512 bytes)
+            body = bytes(rng.integers(0, 256, int(rng.integers(200, 1500)), dtype=np.uint8))
+            s = b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + body + bytes(7) + b"\x01"
+        else:
+            s = o.encode(orc.synth(w, h, ch, ["mixed", "icon", "photo"][k % 3], seed=12, img=k), w, h, ch, 1)
+        base.append(s)
+    n = 2304
+    streams = [base[i % len(base)] for i in range(n)]
+    for oc in (4, 3):
+        wants = [o.decode(s, oc)[0] for s in base]
+        slot = max(len(s) for s in base) + 32
+        buf = np.zeros((n, slot), dtype=np.uint8)
+        for i, s in enumerate(streams):
+            buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+        dec = sq.DecodePlan(torch.from_numpy(buf).cuda(), [len(s) for s in streams], w, h, oc)
+        dec.launch()
+        res = dec.results()
+        out = dec.out.cpu().numpy()
+        for i in range(n):
+            want = wants[i % len(base)]
+            if want is None:
+                assert res["status"][i] != 0, (oc, i)
+            else:
+                assert res["status"][i] == 0 and out[i].tobytes() == want.tobytes(), (oc, i)
+        dec.close()
