@@ -422,6 +422,13 @@ def run_rank(args):
     dev = torch.device("cuda", local)
     s, ch = args.size, 4
     if c5:
+        # pixels + worst-case encode slots (channels + 1 bytes per pixel) + decoded pixels: the whole suite is 345 GB, i.e. it
+        # needs two GPUs of 288 GB (BASELINE.json quotes it on eight)
+        need = sum(im.pixels * (3 * im.channels + 1) + 1024 for im in mine)
+        have = torch.cuda.mem_get_info(dev)[0]
+        if need > 0.95 * have:
+            raise SystemExit(f"bench.py --config c5: rank {rank} of {world} would need {need / 2**30:.0f} GiB of device memory for {len(mine)} images, "
+                             f"{have / 2**30:.0f} GiB are free: use more GPUs (--gpus N) or fewer images (--images M)")
         wl = Suite(sq, torch, dev, mine)
     else:
         wl = Uniform(sq, torch, dev, len(mine), s, s, ch, "mixed", mine[0] if len(mine) else 0)
