@@ -92,6 +92,13 @@ class Plan:
         self._h = C.c_void_p()
         check(self.lib.sqoa_hip_plan_create(device, kind, self._jobs, self.n, C.byref(self._h)), "sqoa_hip_plan_create")
 
+    def update(self, jobs: Sequence[Job]):
+        """sqoa_hip_plan_update: a new job table (at most as many jobs as the plan was created for) without re-allocating."""
+        jobs = list(jobs)
+        arr = (Job * max(len(jobs), 1))(*jobs)
+        check(self.lib.sqoa_hip_plan_update(self._h, arr, len(jobs)), "sqoa_hip_plan_update")
+        self._jobs, self.n = arr, len(jobs)
+
     def launch(self, stream: int = 0):
         check(self.lib.sqoa_hip_plan_launch(self._h, C.c_void_p(stream) if stream else None), "sqoa_hip_plan_launch")
 

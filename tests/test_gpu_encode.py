@@ -537,3 +537,50 @@ def test_batch_encode_cuts_large_images_into_strips_on_the_device(sq, orc, monke
     for k, (name, px, ch) in enumerate(cases):
         assert got[knob][k] == wants[k], (name, "strips")
         assert got["0"][k] == wants[k], (name, "one workgroup")
+
+
+def test_plan_update_switches_between_the_routes(sq, orc):
+    """sqoa_hip_plan_update on one encode and one decode plan: a lone large image (strips on the device / three chip-wide
+    passes), many small ones (one workgroup each), a mix, and a large one again -- the tables of the chip-wide routes are
+    rebuilt (and grown) by every update.  Every stream and every decoded image against the reference."""
+    import torch
+
+    from seqoia_amd import Desc, Job
+    from seqoia_amd._lib import DECODE, ENCODE
+
+    o = orc.best()
+    cap = 24
+    rounds = [[(640, 480, 4, "mixed")],
+              [(64, 48, 3 + (k & 1), ["icon", "mixed", "photo"][k % 3]) for k in range(cap)],
+              [(800, 600, 4, "photo"), (512, 512, 3, "icon")] + [(40, 40, 4, "mixed")] * 6,
+              [(1024, 768, 3, "mixed")]]
+    slot = sq.encode_bound(Desc(1024, 768, 4, 0, 0))
+    src = torch.empty((cap, 1024 * 768 * 4), dtype=torch.uint8, device="cuda")
+    enc_out = torch.zeros((cap, slot), dtype=torch.uint8, device="cuda")
+    dec_out = torch.zeros((cap, 1024 * 768 * 4), dtype=torch.uint8, device="cuda")
+    dummy = [Job(src[i].data_ptr(), enc_out[i].data_ptr(), 0, slot, Desc(8, 8, 4, 0, 0), 0) for i in range(cap)]
+    enc = sq.Plan(ENCODE, dummy)
+    dec = sq.Plan(DECODE, [Job(enc_out[i].data_ptr(), dec_out[i].data_ptr(), 64, 1024 * 768 * 4, Desc(0, 0, 0, 0, 0), 0) for i in range(cap)])
+    for r, shapes in enumerate(rounds):
+        raws = []
+        for k, (w, h, ch, cls) in enumerate(shapes):
+            raw = orc.synth(w, h, ch, cls, 21 + r, k)
+            src[k, : raw.size] = torch.from_numpy(raw).cuda()
+            raws.append(raw)
+        enc.update([Job(src[k].data_ptr(), enc_out[k].data_ptr(), 0, slot, Desc(w, h, ch, 0, 0), 0) for k, (w, h, ch, _) in enumerate(shapes)])
+        enc.launch()
+        res = enc.results()
+        assert (res["status"] == 0).all(), (r, res["status"].tolist())
+        for k, (w, h, ch, _) in enumerate(shapes):
+            assert bytes(enc_out[k, : int(res["len"][k])].cpu().numpy()) == o.encode(raws[k], w, h, ch, 0), (r, k)
+        dec.update([Job(enc_out[k].data_ptr(), dec_out[k].data_ptr(), int(res["len"][k]), w * h * ch, Desc(w, h, ch, 0, 0), 0)
+                    for k, (w, h, ch, _) in enumerate(shapes)])
+        dec.launch()
+        dres = dec.results()
+        assert (dres["status"] == 0).all(), (r, dres["status"].tolist())
+        for k, (w, h, ch, _) in enumerate(shapes):
+            assert bytes(dec_out[k, : w * h * ch].cpu().numpy()) == raws[k].tobytes(), (r, k)
+    with pytest.raises(Exception):
+        enc.update(dummy + dummy[:1])   # more jobs than the plan was created for
+    enc.close()
+    dec.close()
