@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Differential soak on the GPU box: plans of random image lists (sizes 1x1 .. 900x700, 3 / 4 channels, the three synthetic
+classes plus low-entropy noise with long runs, both wire formats) through EncodeList / DecodeList under every forcing of the
+routes (SQOA_HIP_STRIPS, SQOA_HIP_MULTIPASS), every stream and every decoded image against the reference (oracle/_ref).
+usage: soak.py [rounds] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, seqoia_amd as sq
+from oracle import pyoracle as po
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+o = po.best()
+checked = 0
+for r in range(rounds):
+    n = int(rng.choice([1, 2, 5, 17, 40]))
+    imgs = []
+    for k in range(n):
+        big = rng.random() < 0.25
+        w = int(rng.integers(200, 900)) if big else int(rng.integers(1, 120))
+        h = int(rng.integers(150, 700)) if big else int(rng.integers(1, 90))
+        ch = int(rng.choice([3, 4]))
+        kind = int(rng.integers(0, 5))
+        if kind < 3:
+            raw = po.synth(w, h, ch, ["mixed", "icon", "photo"][kind], seed=100 + r, img=k)
+        elif kind == 3:   # few colours, long runs, repeats: INDEX / RUN heavy
+            pal = rng.integers(0, 256, size=(int(rng.integers(2, 9)), ch), dtype=np.uint8)
+            idx = np.repeat(rng.integers(0, len(pal), size=w * h // 7 + 2), rng.integers(1, 40, size=w * h // 7 + 2))[: w * h]
+            idx = np.concatenate([idx, np.zeros(w * h - len(idx), dtype=idx.dtype)])
+            raw = pal[idx].reshape(-1)
+        else:
+            raw = rng.integers(0, 256, size=w * h * ch, dtype=np.uint8)
+            a = int(rng.integers(0, max(1, w * h - 1)))
+            raw.reshape(-1, ch)[a : a + int(rng.integers(1, 70000))] = raw.reshape(-1, ch)[a]
+        imgs.append((w, h, ch, np.ascontiguousarray(raw)))
+    for mode in (0, 1):
+        wants = [o.encode(raw, w, h, ch, mode) for (w, h, ch, raw) in imgs]
+        for strips, passes in (("", ""), ("1", "1"), ("0", "0")):
+            os.environ["SQOA_HIP_STRIPS"], os.environ["SQOA_HIP_MULTIPASS"] = strips, passes
+            images = [(torch.from_numpy(raw).cuda(), sq.Desc(w, h, ch, 0, mode)) for (w, h, ch, raw) in imgs]
+            enc = sq.EncodeList(images)
+            enc.launch()
+            res = enc.results()
+            got = enc.streams()
+            for k, wnt in enumerate(wants):
+                assert res["status"][k] == 0 and got[k] == wnt, ("encode", r, mode, strips, k, imgs[k][:3])
+            base = enc.out.data_ptr()
+            for oc in (0, 4, 3):
+                items = [(base + enc.offsets[k], len(wants[k]), w, h, oc if oc else ch) for k, (w, h, ch, _) in enumerate(imgs)]
+                dec = sq.DecodeList(items)
+                dec.launch()
+                dres = dec.results()
+                for k, (w, h, ch, raw) in enumerate(imgs):
+                    occ = oc if oc else ch
+                    want = o.decode(wants[k], occ)[0]
+                    have = dec.out[dec.offsets[k] : dec.offsets[k] + w * h * occ].cpu().numpy()
+                    assert dres["status"][k] == 0 and have.tobytes() == want.tobytes(), ("decode", r, mode, passes, oc, k, imgs[k][:3])
+                    checked += 1
+                dec.close()
+            enc.close()
+    print(f"round {r}: {n} images ok", flush=True)
+print(f"soak ok: {checked} decoded images and their streams identical to the reference")
