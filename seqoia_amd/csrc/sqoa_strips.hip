@@ -3,9 +3,8 @@
 // One image is one workgroup, i.e. one compute unit's instruction issue: 0.575 ms per Mpixel however idle the other 255 CUs
 // are (a lone 3840x2160 image: 4.5 ms).  The encoder already takes STRIP jobs (sqoa_hip.h: a stretch of an image's pixels,
 // no header, no end marker, the pixel in front as predecessor); a strip must start at a pixel that differs from its
-// predecessor so that no run (seqoia.h:544-561) crosses the cut.  The legacy sqoa_encode finds such cuts on the host
-// (sqoa_host.c); a batch plan's pixels are in device memory, so here the same is done by three small kernels around the
-// unchanged encoder:
+// predecessor so that no run (seqoia.h:544-561) crosses the cut.  A plan's pixels are in device memory, so the cuts are found
+// there, by three small kernels around the unchanged encoder (the legacy sqoa_encode is a plan of one job and gets the same):
 //
 //   strip_cut_kernel   one wave per nominal cut: the first pixel at or behind it that differs from its predecessor, searched
 //                      up to the next nominal cut (none: the stretch is the inside of one run and joins the strip in front);
