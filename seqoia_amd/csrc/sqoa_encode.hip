@@ -1134,4 +1134,15 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
     return hipGetLastError();
 }
 
+// Many SMALL images (the plan decides: sqoa_runtime.hip): one wave per image.  An image of a few sub-tiles gives eight waves
+// nothing to share but the chain hops and the workgroup's prologue: 16 384 icons of 128 x 128 0.65 -> 0.41 ms, 4096 of
+// 64 x 64 66 -> 45 us; from 256 x 256 on the shapes are equal (tools/time_tiny.py).
+extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                               sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (qoi) hipLaunchKernelGGL((encode_kernel<1, true>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results);
+    else hipLaunchKernelGGL((encode_kernel<1, false>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results);
+    return hipGetLastError();
+}
+
 }  // namespace sqoa

@@ -17,6 +17,8 @@
 
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                               sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
@@ -53,6 +55,14 @@ extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_
 #ifndef SQOA_ST_WGS
 #define SQOA_ST_WGS 2048u          // strips aimed at per launch: two rounds of workgroups on the chip
 #endif
+// Encode: images of at most SQOA_ENC_SMALL_PX pixels get one wave each when a plan holds at least SQOA_ENC_SMALL_MIN of them
+// (sqoa_encode.hip, sqoa_launch_encode_small; a few small images are done sooner by eight waves each).
+#ifndef SQOA_ENC_SMALL_PX
+#define SQOA_ENC_SMALL_PX 16384ull
+#endif
+#ifndef SQOA_ENC_SMALL_MIN
+#define SQOA_ENC_SMALL_MIN 512u
+#endif
 #ifndef SQOA_DP_MIN_BYTES
 #define SQOA_DP_MIN_BYTES (16u << 10)
 #endif
@@ -80,6 +90,7 @@ struct sqoa_hip_plan {
     sqoa_hip_result* d_init = nullptr;  // results as they must read before a launch (BADARG rows pre-filled)
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
+    int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
@@ -207,8 +218,9 @@ static bool encode_job_ok(const sqoa_hip_job& j) {
 // so of a batch that fits the chip at once (four streams per CU) CU k gets ranks k, C + k, 2C + k, 3C + k of a sorted list:
 // CU 0 would get the largest stream of every quarter.  Boustrophedon order evens the CUs' loads out (headline decode: max / mean
 // CU load 1.026 -> 1.001, 3.74 -> 3.70 ms).
-static void snake(std::vector<int>& v, size_t first, int cus) {
-    for (size_t a = first + cus; a < v.size(); a += 2 * (size_t)cus) std::reverse(v.begin() + a, v.begin() + std::min(v.size(), a + cus));
+static void snake(std::vector<int>& v, size_t first, int cus, size_t last = (size_t)-1) {
+    if (last > v.size()) last = v.size();
+    for (size_t a = first + cus; a < last; a += 2 * (size_t)cus) std::reverse(v.begin() + a, v.begin() + std::min(last, a + cus));
 }
 
 // Dispatch order of a decode plan's streams and the route each takes: pure host arithmetic, no device needed.
@@ -311,8 +323,19 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     if (p->kind == SQOA_HIP_ENCODE) {
         // largest image first (see sqoa_hip_decode_route), then boustrophedon; the QOI-compat list as it is
         auto npx = [&](int i) { return (unsigned long long)jobs[i].desc.width * jobs[i].desc.height; };
-        std::stable_sort(ids_b.begin(), ids_b.end(), [&](int a, int b) { return npx(a) > npx(b); });
-        snake(ids_b, 0, cus);
+        // Many SMALL images get one wave each instead of eight (sqoa_launch_encode_small): they sit at the end of a list sorted
+        // by size, and each part of the list is put into boustrophedon order by itself.
+        auto split_small = [&](std::vector<int>& v, size_t first) -> int {
+            std::stable_sort(v.begin() + first, v.end(), [&](int a, int b) { return npx(a) > npx(b); });
+            size_t cut = v.size();
+            while (cut > first && npx(v[cut - 1]) <= SQOA_ENC_SMALL_PX) --cut;
+            if (v.size() - cut < SQOA_ENC_SMALL_MIN) cut = v.size();
+            snake(v, first, cus, cut);
+            snake(v, cut, cus);
+            return (int)(v.size() - cut);
+        };
+        p->n_sqoa_small = 0;
+        p->n_qoi_small = split_small(ids_b, 0);
         if (!ids_a.empty()) {
             // SQOA_HIP_STRIPS=0 / =1 in the environment: never / every image that is large enough (tests and measurements).  A
             // caller that sends strip jobs of its own (sqoa_host.c) has done the cutting already.
@@ -335,6 +358,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 for (uint32_t q = 0; q < ns; ++q) st_strips.push_back({(uint32_t)k, q});
                 st_ws += (((size_t)npx(i) * (ch + 1) + 255) & ~(size_t)255) + (size_t)ns * 512 + 512;
             }
+            p->n_sqoa_small = split_small(ids_a, (size_t)n_cut);
         }
     } else if (!ids_a.empty()) {
         unsigned long long bytes = 0;
@@ -489,8 +513,10 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
     if (p->kind == SQOA_HIP_ENCODE) {
         HIP_TRY(sqoa_launch_encode_strips(p->d_jobs, p->d_results, &p->st, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->st.n_images, p->n_sqoa - p->st.n_images, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->st.n_images, p->n_sqoa - p->st.n_images - p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, p->d_ids + p->n_sqoa - p->n_sqoa_small, p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, p->d_ids + p->n_sqoa + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
         HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }

@@ -584,3 +584,31 @@ def test_plan_update_switches_between_the_routes(sq, orc):
         enc.update(dummy + dummy[:1])   # more jobs than the plan was created for
     enc.close()
     dec.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_many_small_images_get_one_wave_each(sq, orc, mode):
+    """A plan with at least 512 images of at most 16 384 pixels encodes those with one wave per image
+    (encode_kernel<1, ...>), the larger ones of the same plan with eight: every stream against the reference, in the job
+    order the caller gave (the plan's own order is largest first, small ones last)."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(31 + mode)
+    shapes = []
+    for k in range(640):
+        w, h = int(rng.integers(1, 129)), int(rng.integers(1, 129))
+        shapes.append((w, h, (3, 4)[k & 1], ["icon", "mixed", "photo"][k % 3]))
+    shapes[5] = (300, 200, 4, "mixed")       # larger than the small shape: eight waves
+    shapes[77] = (640, 480, 3, "photo")      # large enough to be cut into strips when it is SQOA-native
+    shapes[300] = (128, 128, 4, "icon")      # exactly at the limit
+    raws = [orc.synth(w, h, ch, cls, 41, k) for k, (w, h, ch, cls) in enumerate(shapes)]
+    images = [(torch.from_numpy(raw).cuda(), sq.Desc(w, h, ch, 0, mode)) for raw, (w, h, ch, _) in zip(raws, shapes)]
+    plan = sq.EncodeList(images)
+    plan.launch()
+    res = plan.results()
+    got = plan.streams()
+    assert (res["status"] == 0).all()
+    for k, (w, h, ch, _) in enumerate(shapes):
+        assert got[k] == o.encode(raws[k], w, h, ch, mode), (k, w, h, ch)
+    plan.close()
