@@ -521,7 +521,7 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
 
 }  // namespace sqoa
 
-extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n,
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
                                               sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
@@ -538,7 +538,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     hipError_t e = hipSuccess;
     if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, stream);
     if (e != hipSuccess) return e;
-    e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, d_results, stream);
+    e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, small, d_results, stream);
     if (e != hipSuccess) return e;
 #if !defined(SQOA_QDEC) || SQOA_QDEC
     e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);

@@ -594,9 +594,9 @@ def test_mono_streams_all_channel_args(sq, orc):
         dec.close()
 
 
-def test_many_short_qoi_streams_take_the_small_workgroup_shape(sq, orc):
-    """More than 2048 short streams in one plan: the QOI-compat decoder runs with fewer waves per image (more images at once;
-    decode_qoi_kernel<SQOA_QDEC_W_SMALL>).  Random-body streams (INDEX on an empty table, runs, every op length) and encoder
+def test_many_short_streams_take_the_small_workgroup_shapes(sq, orc):
+    """More than 2048 short streams in one plan: both decoders run with fewer waves per image (more images at once;
+    decode_wave_kernel<SQOA_DEC_W_SMALL, 0>, decode_qoi_kernel<SQOA_QDEC_W_SMALL>).  Random-body streams (INDEX on an empty table, runs, every op length) and encoder
     output, RGB and RGBA, to 3 and 4 channels; every stream against the reference."""
     import torch
 
@@ -606,11 +606,13 @@ def test_many_short_qoi_streams_take_the_small_workgroup_shape(sq, orc):
     base = []
     for k in range(48):
         ch = (3, 4)[k & 1]
-        if k % 3 == 0:   # random bytes behind a valid QOI-compat header (1..3 chunks of 512 bytes)
+        native = (k // 6) & 1   # both wire formats: the SQOA wave decoder has a small shape too (four waves per stream)
+        if k % 3 == 0:   # random bytes behind a valid header (1..3 chunks of 512 bytes)
             body = bytes(rng.integers(0, 256, int(rng.integers(200, 1500)), dtype=np.uint8))
-            s = b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + body + bytes(7) + b"\x01"
+            head = (b"Sqoa", b"qoif")[1 - native] + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0])
+            s = head + (b"\x31" if native else b"") + body + bytes(7) + b"\x01"
         else:
-            s = o.encode(orc.synth(w, h, ch, ["mixed", "icon", "photo"][k % 3], seed=12, img=k), w, h, ch, 1)
+            s = o.encode(orc.synth(w, h, ch, ["mixed", "icon", "photo"][k % 3], seed=12, img=k), w, h, ch, 1 - native)
         base.append(s)
     n = 2304
     streams = [base[i % len(base)] for i in range(n)]
