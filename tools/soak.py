@@ -13,10 +13,10 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 o = po.best()
 checked = 0
 for r in range(rounds):
-    n = int(rng.choice([1, 2, 5, 17, 40]))
+    n = int(rng.choice([1, 2, 5, 17, 40, 700]))   # (700: enough small images for the one-wave encode shape)
     imgs = []
     for k in range(n):
-        big = rng.random() < 0.25
+        big = rng.random() < (0.01 if n > 100 else 0.25)
         w = int(rng.integers(200, 900)) if big else int(rng.integers(1, 120))
         h = int(rng.integers(150, 700)) if big else int(rng.integers(1, 90))
         ch = int(rng.choice([3, 4]))
