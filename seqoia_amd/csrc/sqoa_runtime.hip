@@ -425,9 +425,13 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         }
         if (e == hipSuccess) e = grow(&p->st.d_ws, &p->st.ws_bytes, st_ws, 1);
         if (e != hipSuccess) {
+            // no memory for the strips' workspace (5 bytes per pixel of the images cut): not an error -- the images stay where they
+            // are in the id list, its largest entries, and get a workgroup each like the rest
+            (void)hipGetLastError();
             p->st.n_images = p->st.n_strips = 0;
-            return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan: tables and workspace of the strip encode", e);
+            st_images.clear();
         }
+        if (st_images.empty()) goto strips_done;
         for (auto& r : st_images) r.ws += (unsigned long long)(uintptr_t)p->st.d_ws;
         if ((e = hipMemcpy(p->st.d_images, st_images.data(), sizeof(st_image_row) * ni, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(p->st.d_strips, st_strips.data(), sizeof(st_strip_row) * ns, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -435,13 +439,16 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the strip encode, upload", e);
         }
     }
+strips_done:
     if (!dp_images.empty()) {
         if ((e = grow(&p->dp.d_flags, &p->dp_flags_cap, dp_images.size(), sizeof(uint32_t))) != hipSuccess ||
             (e = grow(&p->dp.d_images, &p->dp_images_cap, dp_images.size(), sizeof(dp_image_row))) != hipSuccess ||
             (e = grow(&p->dp.d_wgs, &p->dp_wgs_cap, dp_wgs.size(), sizeof(dp_wg_row))) != hipSuccess ||
             (e = grow(&p->dp.d_tab, &p->dp_tab_cap, dp_rows, dp_row_bytes)) != hipSuccess) {
+            // (no memory for the tables: not an error -- the streams are decoded one workgroup each like the rest)
+            (void)hipGetLastError();
             p->dp.n_images = p->dp.n_wgs = 0;
-            return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan: tables of the multi-pass decode", e);
+            return 0;
         }
         if ((e = hipMemcpy(p->dp.d_images, dp_images.data(), sizeof(dp_image_row) * dp_images.size(), hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(p->dp.d_wgs, dp_wgs.data(), sizeof(dp_wg_row) * dp_wgs.size(), hipMemcpyHostToDevice)) != hipSuccess) {
