@@ -79,3 +79,15 @@ void *sqoa_decode(const void *data, int size, sqoa_desc *desc, int channels);
 }
 #endif
 #endif /* SQOA_H */
+
+/* What the reference's implementation section gives its callers besides the four
+ * definitions: <stdlib.h> and <string.h> (reference seqoia.h:386-388; sqoafuzz.c:29
+ * calls free() on the strength of it) and <stdio.h> (seqoia.h:811-812).  Like the
+ * reference's, this part sits outside the include guard. */
+#ifdef SQOA_IMPLEMENTATION
+#include <stdlib.h>
+#include <string.h>
+#ifndef SQOA_NO_STDIO
+#include <stdio.h>
+#endif
+#endif
