@@ -48,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="capture the step once into a HIP graph and replay it (same time: launch overhead is not what bounds the step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier/MAX (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--rehearsal", action="store_true", help="allow more ranks than visible devices (ranks share GPUs); the JSON line is marked as a rehearsal")
     ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report their shard (no GPU): launcher / sharding rehearsal")
     return ap.parse_args(argv)
 
@@ -55,26 +56,61 @@ def parse_args(argv=None):
 # ---- launcher: --gpus N without torchrun -----------------------------------------------------------------------------
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, args, argv, limit_s=1500.0):
     """Start n rank processes of this script and relay rank 0's stdout.  Nothing here may touch a GPU API: a process
-    that has initialised HIP must not fork/exec the ranks (and this parent never imports torch)."""
+    that has initialised HIP must not fork/exec the ranks (and this parent never imports torch).  The parent runs the
+    reference leg on the host cores once, BEFORE the ranks exist (they would compete for the cores, and rank 0 hosts the
+    rendezvous store the others wait for), and hands it to rank 0 in a file.  All children are polled: when one fails or the
+    time limit passes, the others are terminated (they would sit in the rendezvous or a barrier otherwise)."""
+    import tempfile
+
+    cpu_file = None
+    if not (args.no_cpu or args.dry_run):
+        cpu = cpu_baseline(args.size, args.size, 4)
+        fd, cpu_file = tempfile.mkstemp(prefix="sqoa_bench_cpu_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(cpu, f)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, out0 = [], tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if cpu_file:
+            env["SQOA_BENCH_CPU_JSON"] = cpu_file
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t_end, bad = time.time() + limit_s, []
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or all(rc == 0 for rc in rcs):
+                break
+            if time.time() > t_end:
+                bad = [(r, "time limit") for r, rc in enumerate(rcs) if rc is None]
+                break
+            time.sleep(0.05)
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_kill = time.time() + 5.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        if cpu_file:
+            os.unlink(cpu_file)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.exit(f"bench.py: ranks failed (rank, exit code): {bad}")
+        sys.exit(f"bench.py: ranks failed (rank, exit code): {bad}; the other ranks were stopped")
 
 
 # ---- the reference on the host cores -----------------------------------------------------------------------------------
@@ -337,29 +373,70 @@ def secondary(sq, torch, dev, headline, k=5):
     # (DESIGN.md 3.1b, 3.2b); one workgroup per image would be one compute unit's speed (0.57 / 2.0 ms per Mpixel)
     row("one 3840x2160 RGBA image alone, qoi_compat=0", Uniform(sq, torch, dev, 1, 3840, 2160, 4, "mixed", 0))
     row("16 x 1024x1024 RGBA, qoi_compat=0", Uniform(sq, torch, dev, 16, 1024, 1024, 4, "mixed", 0))
+    # BASELINE.json configs[4] as rank 0 of 8 sees it: its LPT shard of the 65 536 suite-shaped images in one plan per direction
+    from seqoia_amd import suite
+
+    row("C5 rank 0 of 8: LPT shard of the 65536 suite-shaped images (8192 images, 64x64 .. 3840x2160, 3 and 4 channels), qoi_compat=0",
+        Suite(sq, torch, dev, suite.shard(suite.C5_IMAGES, 8, 0)))
+    out["legacy sqoa_encode / sqoa_decode on one 1024x1024 RGBA host image"] = legacy_calls(sq, headline)
     return out
 
 
-def traffic_from_profile(kernel):
+def legacy_calls(sq, headline, runs=10):
+    """The "sqoa:" row a relinked sqoabench prints: the four-symbol API on HOST buffers, one image per call, protocol of
+    BENCHMARK_FN (sqoabench.c:394-406: one discarded warm-up run, mean of `runs`; malloc by the library and free by the caller
+    inside the timed region, sqoabench.c:490-494 decode to 4 channels, :527-538 encode).  PCIe copies included by nature."""
+    import ctypes as C
+
+    from seqoia_amd import _lib
+
+    lib = _lib.load()
+    px = headline.px[0].cpu().numpy().copy()
+    h, w, ch = px.shape
+    d, n, dd = sq.Desc(w, h, ch, 0, 0), C.c_int(0), sq.Desc()
+    p = lib.sqoa_encode(px.ctypes.data, C.byref(d), C.byref(n))
+    assert p, "legacy sqoa_encode failed"
+    enc = C.string_at(p, n.value)
+    _lib.c_free(p)
+    t_enc = t_dec = 0.0
+    for i in range(-1, runs):
+        a = time.perf_counter()
+        q = lib.sqoa_decode(enc, len(enc), C.byref(dd), 4)
+        _lib.c_free(q)
+        b = time.perf_counter()
+        q = lib.sqoa_encode(px.ctypes.data, C.byref(d), C.byref(n))
+        _lib.c_free(q)
+        c = time.perf_counter()
+        if i >= 0:
+            t_dec += b - a
+            t_enc += c - b
+    return {"encode_ms": round(t_enc / runs * 1e3, 4), "decode_ms": round(t_dec / runs * 1e3, 4),
+            "encode_mpps": round(w * h * runs / t_enc / 1e6, 1), "decode_mpps": round(w * h * runs / t_dec / 1e6, 1),
+            "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of 10 runs, malloc+free timed, host buffers (H2D + kernels + D2H per call)"}
+
+
+def traffic_from_profile(kernel, images, size):
     """HBM bytes per launch from the committed rocprofv3 PMC summary, only when it was taken from THIS kernel source
-    (the summary records the hash of seqoia_amd/csrc); otherwise None."""
+    (the summary records the hash of seqoia_amd/csrc) on the same image shape; scaled to this rank's number of images (the
+    images are independent and equal in size: traffic is per image); otherwise None."""
     import hashlib
 
     pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
-    if not os.path.exists(pmc):
+    if not os.path.exists(pmc) or images <= 0:
         return None, None
     d = json.load(open(pmc))
     hsh = hashlib.sha256()
     src = os.path.join(ROOT, "seqoia_amd", "csrc")
     for f in sorted(os.listdir(src)):
         hsh.update(open(os.path.join(src, f), "rb").read())
-    if d.get("csrc_sha256") != hsh.hexdigest():
+    if d.get("csrc_sha256") != hsh.hexdigest() or d.get("size", 1024) != size:
         return None, None
     k = d["kernels"].get(kernel)
     if not k:
         return None, None
     # gfx950: FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md, HBM); KB
-    return int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024), "profiles/pmc_hbm_latest.json"
+    per_launch = (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024
+    return int(per_launch * images / d.get("images", 1024)), "profiles/pmc_hbm_latest.json"
 
 
 # ---- one rank --------------------------------------------------------------------------------------------------------
@@ -388,6 +465,8 @@ def run_rank(args):
     if args.dry_run:  # rendezvous + shard report only: rehearses the launcher and the partition without a GPU
         import torch.distributed as dist
 
+        if os.environ.get("SQOA_BENCH_FAULT_RANK") == str(rank):  # fault injection for the launcher's tests: this rank dies before the rendezvous
+            sys.exit(3)
         if world > 1:
             dist.init_process_group("gloo")
         cnt = len(mine)
@@ -398,9 +477,16 @@ def run_rank(args):
             dist.destroy_process_group()
         return
 
+    # The reference on the host cores, in the same run as every point of the 1..N curve (north-star).  Rank 0, before this
+    # process touches any GPU API (it starts worker processes) and before the rendezvous, during which the other ranks only
+    # wait; under bench.py's own launcher the parent has already run it (launch_ranks) and left it in a file.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.size, args.size, 4)  # before any GPU API: it starts worker processes
+    if rank == 0 and not args.no_cpu:
+        handed = os.environ.get("SQOA_BENCH_CPU_JSON")
+        if handed and os.path.exists(handed):
+            cpu = json.load(open(handed))
+        else:
+            cpu = cpu_baseline(args.size, args.size, 4)
 
     import torch
 
@@ -408,7 +494,11 @@ def run_rank(args):
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
-    local = local % max(torch.cuda.device_count(), 1)  # rehearsal on a 1-GPU box: ranks share the device
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.rehearsal:
+        sys.exit(f"bench.py: {world} ranks but {ndev} visible device(s): a scaling number from ranks that share a GPU means nothing "
+                 f"(--rehearsal runs it anyway and marks the line)")
+    local = local % max(ndev, 1)  # --rehearsal on a smaller box: ranks share devices, the line says so
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -513,6 +603,7 @@ def run_rank(args):
             "workload": workload,
             "images_rank0": wl.n,
             "images_total": n_global,
+            "devices_used": min(world, ndev),
             "pixels_total": int(total_px),
             "encoded_bytes_total": int(total_enc),
             "encoded_bytes_check": int(sum(all_lens)),  # from the gathered per-image lengths: equals encoded_bytes_total
@@ -526,8 +617,11 @@ def run_rank(args):
     }
     # Both kernels are HBM-bound by their algorithmic bytes; the decoder is the dominant one by time, the
     # encoder is the one the north-star's target (>= 50 % of the HBM-read roofline) is stated on.
-    enc_traffic, src = traffic_from_profile("encode")
-    dec_traffic, _ = traffic_from_profile("decode")
+    if c5:
+        enc_traffic = dec_traffic = src = None
+    else:
+        enc_traffic, src = traffic_from_profile("encode", wl.n, s)
+        dec_traffic, _ = traffic_from_profile("decode", wl.n, s)
     dominant = "decode" if dec_ms >= enc_ms else "encode"
     roof_enc = {
         "kernel": "sqoa::encode_kernel<8,false>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -549,6 +643,8 @@ def run_rank(args):
         out["roofline"]["traffic_source"] = src
     out["roofline"]["encode"] = roof_enc
     out["roofline"]["decode"] = roof_dec
+    if world > ndev:
+        out["rehearsal"] = f"{world} ranks on {ndev} device(s): not a scaling measurement"
     if rank == 0 and world == 1 and not c5 and not args.no_secondary:
         out["config"]["secondary"] = secondary(sq, torch, dev, wl)
     if cpu is not None:
@@ -565,7 +661,7 @@ def main():
         cpu_worker(args.cpu_worker)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args.gpus, sys.argv[1:])
+        launch_ranks(args.gpus, args, sys.argv[1:])
         return
     run_rank(args)
 

@@ -39,6 +39,13 @@ struct sqoa_st_tables {
 
 namespace sqoa {
 
+// Rows of those tables: filled on the host by the plan (sqoa_runtime.hip, plan_fill), read by the kernels -- ONE definition.
+struct dp_image { int jid; uint32_t tab_off, nchunks, nwgs; };   // one multi-pass image: its job, its rows of the table (one per workgroup)
+struct dp_wg { uint32_t img, chunk0; };                           // one workgroup of a pass: image and first chunk
+struct st_image { int jid; uint32_t first, nstrips, npx; unsigned long long ws; };   // strip rows [first, first + nstrips), workspace
+struct st_strip { uint32_t img, k; };
+static_assert(sizeof(dp_image) == 16 && sizeof(dp_wg) == 8 && sizeof(st_image) == 24 && sizeof(st_strip) == 8, "table rows are packed");
+
 // Device addresses arrive as integers in the job table; tell the compiler they are GLOBAL
 // (address space 1) so it emits global_load/global_store, not flat_*.
 typedef const __attribute__((address_space(1))) uint8_t* gcptr8;

@@ -84,8 +84,7 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 
 
 // ---- chip-wide decode of few large streams: the tables of the three passes (MODE 1..3 of decode_wave_kernel) -----------------
-struct dp_image { int jid; uint32_t tab_off, nchunks, nwgs; };         // one multi-pass image: its job, its rows of the table (one per workgroup)
-struct dp_wg { uint32_t img, chunk0; };                                 // one workgroup of a pass: image and first chunk
+// (dp_image, dp_wg: sqoa_common.h)
 // What the LDS chain carries, per workgroup (DP_CHUNKS_PER_WG chunks), in HBM: the composite of its chunks' transition functions,
 // pixel counts and transforms (written by passes 1 and 2), and what enters its first chunk (written by the two scans).
 struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };

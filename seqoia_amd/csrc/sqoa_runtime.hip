@@ -22,7 +22,6 @@ extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
-extern "C" void sqoa_st_layout(size_t* image_row, size_t* strip_row);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes);
 
@@ -308,15 +307,18 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             ids_a.push_back(i);
         }
     }
+    // whatever fails below, the plan must not keep the previous fill's route tables beside the new id list
+    p->st.n_images = p->st.n_strips = 0;
+    p->dp.n_images = p->dp.n_wgs = 0;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
-    struct dp_image_row { int jid; uint32_t tab_off, nchunks, nwgs; };   // = sqoa::dp_image / dp_wg (sqoa_decode_wave.hip)
-    struct dp_wg_row { uint32_t img, chunk0; };
+    typedef sqoa::dp_image dp_image_row;   // (sqoa_common.h: the kernels read the very same structs)
+    typedef sqoa::dp_wg dp_wg_row;
     std::vector<dp_image_row> dp_images;
     std::vector<dp_wg_row> dp_wgs;
     size_t dp_rows = 0, dp_row_bytes = 32;
-    struct st_image_row { int jid; uint32_t first, nstrips, npx; unsigned long long ws; };   // = sqoa::st_image / st_strip (sqoa_strips.hip)
-    struct st_strip_row { uint32_t img, k; };
+    typedef sqoa::st_image st_image_row;
+    typedef sqoa::st_strip st_strip_row;
     std::vector<st_image_row> st_images;
     std::vector<st_strip_row> st_strips;
     size_t st_ws = 0;
@@ -559,6 +561,7 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
 int sqoa_hip_plan_time(sqoa_hip_plan* p, int iters, float* ms_total) {
     if (!p || iters <= 0 || !ms_total) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_time: bad arguments");
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
+    HIP_TRY(plan_wait(p), SQOA_HIP_ELAUNCH);   // a launch on the caller's stream may still be using the result rows and workspaces
     HIP_TRY(hipEventRecord(p->ev0, p->stream), SQOA_HIP_ELAUNCH);
     for (int i = 0; i < iters; ++i) {
         int rc = plan_enqueue(p, p->stream);

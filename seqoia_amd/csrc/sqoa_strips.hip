@@ -17,8 +17,7 @@
 
 namespace sqoa {
 
-struct st_image { int jid; uint32_t first, nstrips, npx; unsigned long long ws; };   // strip rows [first, first + nstrips), workspace
-struct st_strip { uint32_t img, k; };
+// (st_image, st_strip: sqoa_common.h)
 constexpr uint32_t ST_NONE = 0xffffffffu;
 
 SQOA_DEV uint32_t st_nominal(uint32_t npx, uint32_t k, uint32_t s) { return (uint32_t)((unsigned long long)npx * k / s); }
@@ -143,4 +142,4 @@ extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa
     return hipGetLastError();
 }
 
-extern "C" void sqoa_st_layout(size_t* image_row, size_t* strip_row) { *image_row = sizeof(sqoa::st_image); *strip_row = sizeof(sqoa::st_strip); }
+

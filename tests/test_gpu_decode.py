@@ -18,8 +18,12 @@ def sq():
 
 @pytest.fixture(scope="module")
 def orc():
+    """The checker.  On the GPU box it must be the REAL reference (oracle/_ref/libsqoa_ref.so, /root/reference/seqoia.h compiled
+    by oracle/Makefile in the build container; the .so travels with the snapshot): a run that silently fell back to the
+    restatement would still be a parity test, but not the one the documents claim."""
     from oracle import pyoracle as po
 
+    assert po.best().kind == "reference", "oracle/_ref/libsqoa_ref.so did not travel: GPU parity must be checked against the compiled reference"
     return po
 
 
@@ -264,9 +268,10 @@ def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
         del dec, enc
 
 
-def test_c5_rank0_of_8_shard(sq, orc):
-    """BASELINE configs[4] as one of its 8 ranks sees it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
-    LPT-sharded on w*h, rank 0's 8 192 images in ONE encode plan and ONE decode plan (the workload class of
+@pytest.mark.parametrize("rank", [0, 7])
+def test_c5_rank_of_8_shard(sq, orc, rank):
+    """BASELINE configs[4] as the first and the last of its 8 ranks see it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
+    LPT-sharded on w*h, the rank's 8 192 images in ONE encode plan and ONE decode plan (the workload class of
     `bench.py --config c5 --gpus 8`): every status OK, every image round-trips exactly (sqoabench.c:448-455, one result per
     image as in sqoabench.c:575-628), and a sample of streams from every directory is byte-equal to the oracle's."""
     import torch
@@ -274,7 +279,7 @@ def test_c5_rank0_of_8_shard(sq, orc):
     import bench
     from seqoia_amd import suite
 
-    shard = suite.shard(suite.C5_IMAGES, 8, 0)
+    shard = suite.shard(suite.C5_IMAGES, 8, rank)
     assert len(shard) > 8000
     wl = bench.Suite(sq, torch, torch.device("cuda", 0), shard)  # asserts statuses and the round trip of every image
     assert wl.pixels == sum(im.pixels for im in shard)

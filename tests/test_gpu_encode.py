@@ -25,8 +25,10 @@ def sq():
 
 @pytest.fixture(scope="module")
 def orc():
+    """The checker: on the GPU box it must be the compiled reference (oracle/_ref), not the restatement it would fall back to."""
     from oracle import pyoracle as po
 
+    assert po.best().kind == "reference", "oracle/_ref/libsqoa_ref.so did not travel: GPU parity must be checked against the compiled reference"
     return po
 
 

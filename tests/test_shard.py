@@ -102,6 +102,22 @@ def test_bench_gpus_flag_starts_that_many_ranks(n):
     assert out["images_rank0"] == len(shard.contiguous(1024, n, 0))
 
 
+def test_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that dies before the rendezvous must not leave the others waiting for it until some time-out: the launcher
+    polls all children, terminates the rest and exits non-zero at once."""
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SQOA_BENCH_FAULT_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "(1, 3)" in r.stderr, r.stderr
+    assert time.time() - t0 < 60
+
+
 def test_bench_under_an_external_launcher_is_a_rank():
     """Under torch.distributed.run the environment is already there: bench.py must not start ranks of its own."""
     import json

@@ -2,17 +2,22 @@
 """Differential soak on the GPU box: plans of random image lists (sizes 1x1 .. 900x700, 3 / 4 channels, the three synthetic
 classes plus low-entropy noise with long runs, both wire formats) through EncodeList / DecodeList under every forcing of the
 routes (SQOA_HIP_STRIPS, SQOA_HIP_MULTIPASS), every stream and every decoded image against the reference (oracle/_ref).
-usage: soak.py [rounds] [seed]"""
-import os, sys
+usage: soak.py [rounds] [seed] [seconds]      (tests/test_gpu_soak.py runs a 30-second cut of it in the -m gpu suite)"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, seqoia_amd as sq
 from oracle import pyoracle as po
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+t_start = time.time()
 o = po.best()
+assert o.kind == "reference", "the soak compares with the compiled reference (oracle/_ref)"
 checked = 0
 for r in range(rounds):
+    if time.time() - t_start > budget:
+        break
     n = int(rng.choice([1, 2, 5, 17, 40, 700]))   # (700: enough small images for the one-wave encode shape)
     imgs = []
     for k in range(n):
