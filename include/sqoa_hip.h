@@ -40,7 +40,7 @@ typedef struct {
     unsigned int src_size;       /* decode: stream bytes; encode: ignored */
     unsigned int dst_cap;        /* bytes available at dst */
     sqoa_desc desc;
-    unsigned int reserved;       /* 0, or for SQOA-native encode (desc.qoi_compat == 0) SQOA_HIP_JOB_* strip flags */
+    unsigned int reserved;       /* 0, or SQOA_HIP_JOB_* flags: strip flags for SQOA-native encode (desc.qoi_compat == 0), WAVEONLY for decode */
 } sqoa_hip_job;                  /* 40 bytes */
 
 /* Strip jobs: one image encoded by several jobs (several workgroups), each given a stretch of consecutive pixels
@@ -51,6 +51,12 @@ typedef struct {
 #define SQOA_HIP_JOB_NOHEADER 1u /* no header in front of the ops */
 #define SQOA_HIP_JOB_NOEND    2u /* more pixels follow in another job: no end marker, a trailing run is flushed as a run that ends */
 #define SQOA_HIP_JOB_PREV     4u /* the first pixel's predecessor is the pixel in front of src (readable), not (0,0,0,255) */
+/* Decode jobs: the caller has read the stream's header itself (the legacy sqoa_decode has, reference seqoia.h:672-688) and found
+ * an SQOA-native colour stream that goes to 3 or 4 channels.  A plan whose jobs ALL say so launches only the wave-parallel SQOA
+ * decoder and not the QOI-compat / mono / exact kernels behind it.  A stream that needs them after all (a header that says
+ * otherwise, or an SQOA_OP_REF met on the way: decoder-only op, never emitted by the encoder) comes back with
+ * SQOA_HIP_ST_SLOWPATH and nothing decoded; the caller submits it again without the flag. */
+#define SQOA_HIP_JOB_WAVEONLY 8u
 
 /* Per-image outcome, written by the kernels. */
 typedef struct {
@@ -63,7 +69,7 @@ typedef struct {
 #define SQOA_HIP_ST_BADARG    1  /* the reference would return NULL (seqoia.h:465-480, :662-688, :705-707) */
 #define SQOA_HIP_ST_OVERFLOW  2  /* dst_cap too small */
 #define SQOA_HIP_ST_INTERNAL  3  /* chain wait timed out: a bug, never expected */
-#define SQOA_HIP_ST_SLOWPATH  4  /* decode: stream needs the serial path (REF op etc.); handled in-kernel */
+#define SQOA_HIP_ST_SLOWPATH  4  /* decode: stream needs another kernel (REF op etc.); handled inside the launch, seen by callers only for SQOA_HIP_JOB_WAVEONLY jobs */
 
 enum { SQOA_HIP_ENCODE = 0, SQOA_HIP_DECODE = 1 };
 

@@ -89,6 +89,42 @@ SQOA_DEV uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// Poll an 8-byte chain word in LDS -- tag in the high half, value in the low half, always written by ONE ds_write_b64 -- until the tag
+// is `tag`, or `stop` (a tag no work item ever has: the owner has left), or 2^22 polls have failed.  Returns the tag last seen and,
+// in `val`, the low half read by the same poll (the tag dword is read first: the value is at least as new).  Hand-written: the
+// compiler turns the same loop into 25 scalar instructions and 8 branches on the path where the first poll succeeds (a
+// wave-uniform condition lives in a 64-bit lane mask, every exit of the loop gets a flag of its own), and the scalar pipe of a
+// CU is as busy as its vector pipes in these kernels.  Here that path is 2 LDS reads, 2 v_readfirstlane,
+// one compare and one branch.  SLEEP = s_sleep argument between two polls (x 64 cycles).
+template <int SLEEP>
+SQOA_DEV uint32_t chain_poll(const unsigned long long* slot, uint32_t tag, uint32_t stop, uint32_t& val) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned long long*)slot;
+    uint32_t t, v, left, tv, vv;
+    asm volatile(
+        "s_mov_b32 %[left], 0x400000\n"
+        "1:\n\t"
+        "ds_read_b32 %[tv], %[addr] offset:4\n\t"
+        "ds_read_b32 %[vv], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[t], %[tv]\n\t"
+        "s_cmp_eq_u32 %[t], %[tag]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_eq_u32 %[t], %[stop]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_add_i32 %[left], %[left], -1\n\t"
+        "s_cmp_eq_u32 %[left], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep %[slp]\n\t"
+        "s_branch 1b\n"
+        "2:\n\t"
+        "v_readfirstlane_b32 %[v], %[vv]"
+        : [t] "=&s"(t), [v] "=s"(v), [left] "=&s"(left), [tv] "=&v"(tv), [vv] "=&v"(vv)
+        : [addr] "v"(addr), [tag] "s"(tag), [stop] "s"(stop), [slp] "n"(SLEEP)
+        : "memory", "scc");
+    val = v;
+    return t;
+}
+
 SQOA_DEV uint32_t bcast_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 SQOA_DEV uint32_t bcast_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 

@@ -482,9 +482,9 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];
-    const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
-    if (only_slowpath && res->status != SQOA_HIP_ST_SLOWPATH) return;  // only what the wave-parallel kernel declined
+    if (only_slowpath && __builtin_amdgcn_readfirstlane(res->status) != SQOA_HIP_ST_SLOWPATH) return;  // only what the wave-parallel kernel declined: one scalar load otherwise
+    const sqoa_hip_job job = jobs[jid];
     __syncthreads();                                                    // every lane has read the status
     if (only_slowpath && threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;
 
@@ -531,7 +531,7 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
 // streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel.
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int n_multi = dp ? dp->n_images : 0;
@@ -540,6 +540,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, small, d_results, stream);
     if (e != hipSuccess) return e;
+    if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
 #if !defined(SQOA_QDEC) || SQOA_QDEC
     e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
     if (e != hipSuccess) return e;

@@ -120,8 +120,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];
-    const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
+    // Launched over every stream of the plan, after the SQOA kernel: a stream that kernel has decoded (or refused) costs this
+    // workgroup one scalar load -- nothing is built, no barrier is met.  (Wave-uniform: every wave reads the same word, and
+    // nothing in this launch writes it before the __syncthreads below.)
+    if (__builtin_amdgcn_readfirstlane(res->status) != SQOA_HIP_ST_SLOWPATH) return;
+    const sqoa_hip_job job = jobs[jid];
     gcptr8 src0 = (gcptr8)job.src;
 
     // Only what the SQOA kernel handed on (SQOA_HIP_ST_SLOWPATH: header valid, destination large enough) and only QOI-compat

@@ -40,7 +40,7 @@ constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane
 constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step)
 constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded
 constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
-constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
+[[maybe_unused]] constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 
 // Wait for `slot` to carry `tag`; 0 = it does (val set), 1 = the image was handed over (the slot's owner left DEC_ABORT_TAG in
 // it), 2 = timed out.  Integer result codes, not bool: a wave-uniform i1 that flows through a merge is kept as a 64-bit lane
@@ -50,6 +50,7 @@ constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 // predecessor's words sooner or later, so the news goes round the ring), the spin limit a down-counter.
 constexpr uint32_t DEC_ABORT_TAG = 0xffffffffu;   // (chunk tags are chunk numbers + 1 < 2^32 - 1)
 SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t& val) {
+#ifdef SQOA_DEC_C_POLL   // the loop as the compiler makes it (A/B builds)
     uint32_t left = DEC_SPIN_MAX;
     for (;;) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -59,6 +60,10 @@ SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t
         if (--left == 0u) return 2u;
         __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
     }
+#else
+    const uint32_t t = chain_poll<SQOA_DEC_SPIN_SLEEP>(slot, tag, DEC_ABORT_TAG, val);
+    return t == tag ? 0u : t == DEC_ABORT_TAG ? 1u : 2u;
+#endif
 }
 
 SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {

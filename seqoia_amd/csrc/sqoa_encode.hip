@@ -40,6 +40,8 @@ struct EncState {
 
 // Wait until the 8-byte LDS word carries `tag` in its high half; returns the low half.
 SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& st) {
+#ifndef SQOA_ENC_ASM_POLL   // the loop as the compiler makes it: the encoder is short of SGPRs, not of scalar issue slots -- with the hand-written
+                           // poll of the decoder (chain_poll) its SGPR spills went from 79 to 97 and the kernel from 1.57 to 1.59 ms
     for (uint32_t spin = 0; spin < SPIN_MAX; ++spin) {
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t hi = bcast_first((uint32_t)(v >> 32));
@@ -48,6 +50,12 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
     }
     st.bad = 1;
     return 0;
+#else
+    uint32_t val;
+    const uint32_t t = chain_poll<SQOA_ENC_SPIN_SLEEP>(slot, tag, 0xffffffffu, val);   // (no tag is ever 2^32 - 1: sub-tile numbers + 1)
+    if (t != tag) { st.bad = 1; return 0; }
+    return val;
+#endif
 }
 
 SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
@@ -423,7 +431,9 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 #ifndef SQOA_ENC_WPE_QOI
 #define SQOA_ENC_WPE_QOI 4
 #endif
-#define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(QOI ? SQOA_ENC_WPE_QOI : SQOA_ENC_WPE, QOI ? 6 : SQOA_ENC_WPE)))
+// (one wave per image, W = 1: 24 workgroups of 6.7 KB of LDS fit a CU, six waves per SIMD -- asking for eight only earned a
+// "failed to meet occupancy target" from the compiler; the staging buffer, the landing buffer and the run-byte table are 6.6 KB)
+#define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(QOI ? SQOA_ENC_WPE_QOI : (W == 1 ? 6 : SQOA_ENC_WPE), QOI ? 6 : (W == 1 ? 6 : SQOA_ENC_WPE))))
 template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,

@@ -169,8 +169,17 @@ void *sqoa_decode(const void *data, int size, sqoa_desc *desc, int channels) {
     job.desc.width = desc->width;
     job.desc.height = desc->height;
     job.desc.channels = (unsigned char)channels;
+    /* The header has been read right here: an SQOA-native colour stream that goes to 3 or 4 channels needs only the wave-parallel
+     * decoder, and the plan is told so (it then launches nothing else).  A crafted stream with an SQOA_OP_REF in it (seqoia.h:729-738)
+     * comes back undecoded with SLOWPATH and takes the call again through every kernel. */
+    if (!desc->qoi_compat && desc->channels >= 3 && out_ch >= 3) job.reserved = SQOA_HIP_JOB_WAVEONLY;
     sqoa_hip_result res;
-    if (run_job(c, SQOA_HIP_DECODE, &job, &res) || res.status != SQOA_HIP_ST_OK || (size_t)res.len != out_bytes) return NULL;
+    if (run_job(c, SQOA_HIP_DECODE, &job, &res)) return NULL;
+    if (job.reserved && res.status == SQOA_HIP_ST_SLOWPATH) {
+        job.reserved = 0;
+        if (run_job(c, SQOA_HIP_DECODE, &job, &res)) return NULL;
+    }
+    if (res.status != SQOA_HIP_ST_OK || (size_t)res.len != out_bytes) return NULL;
 
     void *out = malloc(out_bytes); /* caller free()s: sqoabench.c:454, :493 */
     if (!out) return NULL;

@@ -19,7 +19,7 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
@@ -91,6 +91,7 @@ struct sqoa_hip_plan {
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
+    int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // encode: the few large images cut into strips
@@ -300,7 +301,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             (jobs[i].desc.qoi_compat ? ids_b : ids_a).push_back(i);
         } else {
             // sqoa_decode's argument checks (seqoia.h:662-668); header checks happen in the kernel
-            if (!jobs[i].src || !jobs[i].dst || jobs[i].desc.channels > 4 || jobs[i].src_size < 22) {
+            if (!jobs[i].src || !jobs[i].dst || jobs[i].desc.channels > 4 || jobs[i].src_size < 22 || (jobs[i].reserved & ~SQOA_HIP_JOB_WAVEONLY)) {
                 init[i].status = SQOA_HIP_ST_BADARG;
                 continue;
             }
@@ -367,6 +368,8 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         std::vector<unsigned int> sizes(ids_a.size());
         for (size_t k = 0; k < ids_a.size(); ++k) { sizes[k] = jobs[ids_a[k]].src_size; bytes += sizes[k]; }
         p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
+        p->wave_only = 1;
+        for (int i : ids_a) if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
@@ -527,7 +530,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, p->d_ids + p->n_sqoa + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }

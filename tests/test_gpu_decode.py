@@ -638,3 +638,48 @@ def test_many_short_streams_take_the_small_workgroup_shapes(sq, orc):
             else:
                 assert res["status"][i] == 0 and out[i].tobytes() == want.tobytes(), (oc, i)
         dec.close()
+
+
+def test_waveonly_jobs_skip_the_other_decoders_and_hand_back_what_they_cannot_take(sq, orc):
+    """SQOA_HIP_JOB_WAVEONLY (what the legacy sqoa_decode sets after reading the header itself): a plan whose jobs all carry it
+    launches only the SQOA wave decoder.  SQOA colour streams decode as ever; a QOI-compat stream and a stream with an
+    SQOA_OP_REF in it come back SLOWPATH for the caller to submit again -- which the legacy call does (the REF KATs above)."""
+    import torch
+
+    from seqoia_amd import Desc, Job
+    from seqoia_amd.api import Plan, DECODE
+
+    o = orc.best()
+    w, h = 96, 40
+    px = orc.synth(w, h, 4, "mixed", 3, 0)
+    s_sqoa, s_qoi = o.encode(px, w, h, 4, 0), o.encode(px, w, h, 4, 1)
+    body = bytes.fromhex("fe010203fe09090945a188a288") + bytes(7) + b"\x01"            # a REF op (0x45), SURVEY appendix B
+    s_ref = b"Sqoa" + (6).to_bytes(4, "big") + (1).to_bytes(4, "big") + bytes([4, 0, 0x31]) + body
+    streams = [s_sqoa, s_qoi, s_ref, s_sqoa]
+    blob = torch.zeros((len(streams), 65536), dtype=torch.uint8, device="cuda")
+    for k, s in enumerate(streams):
+        blob[k, : len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+    out = torch.zeros((len(streams), w * h * 4), dtype=torch.uint8, device="cuda")
+    flag = 8  # SQOA_HIP_JOB_WAVEONLY
+    jobs = [Job(blob[k].data_ptr(), out[k].data_ptr(), len(s), w * h * 4, Desc(0, 0, 4, 0, 0), flag) for k, s in enumerate(streams)]
+    plan = Plan(DECODE, jobs)
+    plan.launch()
+    res = plan.results()
+    assert list(res["status"]) == [0, 4, 4, 0]
+    assert out[0].cpu().numpy().tobytes() == px.tobytes() and out[3].cpu().numpy().tobytes() == px.tobytes()
+    plan.close()
+    # one job without the flag: the plan launches everything again
+    jobs[1] = Job(blob[1].data_ptr(), out[1].data_ptr(), len(s_qoi), w * h * 4, Desc(0, 0, 4, 0, 0), 0)
+    plan = Plan(DECODE, jobs)
+    plan.launch()
+    res = plan.results()
+    assert list(res["status"]) == [0, 0, 0, 0]
+    assert out[1].cpu().numpy().tobytes() == px.tobytes()
+    want, _ = o.decode(s_ref, 4)
+    assert out[2, : 6 * 4].cpu().numpy().tobytes() == want.tobytes()
+    plan.close()
+    # an unknown flag on a decode job is a bad argument
+    bad = Plan(DECODE, [Job(blob[0].data_ptr(), out[0].data_ptr(), len(s_sqoa), w * h * 4, Desc(0, 0, 4, 0, 0), 16)])
+    bad.launch()
+    assert bad.results()["status"][0] == 1
+    bad.close()
