@@ -72,9 +72,11 @@ SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lan
 
 template <int CTRL, int ROWMASK>
 SQOA_DEV Xf xf_scan_step(Xf T) {
-    Xf P;  // the transform of the lanes below, identity where there is none
-    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, false);
-    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, false);
+    Xf P;  // the transform of the lanes below, identity (all zero) where there is none
+    // (all rows enabled: a source lane out of range reads as zero with bound_ctrl, no v_mov of the zero in front of the DPP move)
+    constexpr bool BC = ROWMASK == 0xf;
+    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, BC);
+    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, BC);
     return xf_then(P, T);
 }
 SQOA_DEV Xf wave_xf_scan(Xf T) {
@@ -337,15 +339,22 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         }
     };
 
+    // The prefetched dwords go to the wave's LDS buffer as soon as the current chunk's bytes are dead -- behind the walk, in front
+    // of the chunk's pixel stores -- and not at the top of the next chunk: the wait for the loads there also waited for every
+    // store issued after them (vmcnt counts loads and stores in issue order), i.e. each chunk began by draining the stores of
+    // the chunk before.
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
+        if (lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) lds[lane + 64 * (DEC_NLD - 1)] = stg[DEC_NLD - 1];
+    };
+
     // One chunk.  IN (compile time) = interior chunk: every byte lies inside the chunk area and a successor exists, so the
     // liveness tests and the end-of-stream handling drop out of the hot loop.  Returns false when the image is handed over.
     auto body = [&](auto in_tag, uint32_t c) -> uint32_t {   // 1: go on with the wave's next chunk, 0: the image is done with here
         constexpr bool IN = decltype(in_tag)::value;
         DPHASE(7);
-        // ---- stage the chunk's bytes (+ look-ahead) in LDS; prefetch the wave's next chunk ----
-#pragma unroll
-        for (int k = 0; k < DEC_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
-        if (lane < DEC_LDS_DW - 64 * (DEC_NLD - 1)) lds[lane + 64 * (DEC_NLD - 1)] = stg[DEC_NLD - 1];
+        // ---- the chunk's bytes (+ look-ahead) are in LDS (staged at the end of the wave's previous chunk); prefetch the next one ----
         const bool more = c + W < chunk_end;
         if (more) load_chunk(c + W, stg);
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         uint32_t st_in = seed_st;
         if constexpr (MODE == 1) {
             if (lane == 0) { s_wg[0][c - chunk_first] = G.lo; s_wg[1][c - chunk_first] = G.hi; }
+            if (more) stage();
             return 1u;
         } else {   // inside the workgroup the chunks are chained through LDS in every mode
             // An exit state that does not depend on the entry state is posted before the entry state is known.  That lets a
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             return 0u;
         }
 
+        if (more) stage();   // the walk was the last reader of this chunk's bytes
         DPHASE(2);
         // ---- 3. wave scans: pixel positions and pixel transforms of the lanes below ------------
         const uint32_t cinc = wave_incl_scan(cl);
@@ -510,6 +521,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
             const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
             if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
+#if defined(SQOA_DEC_C_STORES) || defined(SQOA_DBG_DEC_NOSTORE)
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
@@ -523,6 +535,30 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     if (m >> 14) o[1] = v;  // cnt == 2: a literal op and the one-pixel run behind it
 #endif
                 }
+#else
+                // Hand-written: the compiler's version of `if (cnt >= 1) o[0] = v; if (cnt == 2) o[1] = v;` is, per slot, two
+                // s_and_saveexec / s_cbranch_execz / s_or exec triples around stores with 64-bit address arithmetic (7 scalar
+                // instructions + 3 branches + 10 VALU); here the two predicates narrow EXEC directly (v_cmpx), the stores take the
+                // image base from an SGPR pair and a 32-bit byte offset (an image is < 1.6 GB), and EXEC is put back once.  Every
+                // lane of the wave is alive here (wave-uniform control flow, full workgroups): EXEC is all ones on entry.
+                const uint32_t lane_off = lane_p << 2;
+                const unsigned long long obase = job.dst;
+#pragma unroll
+                for (int i = 0; i < DEC_LB; ++i) {
+                    if ((uint32_t)i >= iters) break;
+                    const uint32_t m = meta[i], am = amask[i];
+                    const uint32_t v = add8(lane_px & ~am, val[i]);
+                    const uint32_t off = lane_off + ((m & 0x1fffu) << 2);
+                    asm volatile(
+                        "v_cmpx_lt_u32_e32 vcc, 0x1fff, %[m]\n\t"          // cnt >= 1
+                        "global_store_dword %[off], %[v], %[base]\n\t"
+                        "v_cmpx_lt_u32_e32 vcc, 0x3fff, %[m]\n\t"          // cnt == 2: a literal op and the one-pixel run behind it
+                        "global_store_dword %[off], %[v], %[base] offset:4\n\t"
+                        "s_mov_b64 exec, -1"
+                        :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase) : "memory", "vcc");
+                }
+                asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
+#endif
             } else {
             auto store_ops = [&](auto oc_tag) {
                 constexpr int OC = decltype(oc_tag)::value;
@@ -565,7 +601,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     };
 
     uint32_t c = chunk_first + w;
-    if (c < chunk_end) load_chunk(c, stg);
+    if (c < chunk_end) { load_chunk(c, stg); stage(); }
     const uint32_t nint_all = area / DEC_CHUNK < nchunks - 1 ? area / DEC_CHUNK : nchunks - 1;  // fully live chunks that have a successor
     const uint32_t nint = nint_all < chunk_end ? nint_all : chunk_end;
     uint32_t go = 1;
