@@ -373,6 +373,9 @@ def secondary(sq, torch, dev, headline, k=5):
     # (DESIGN.md 3.1b, 3.2b); one workgroup per image would be one compute unit's speed (0.57 / 2.0 ms per Mpixel)
     row("one 3840x2160 RGBA image alone, qoi_compat=0", Uniform(sq, torch, dev, 1, 3840, 2160, 4, "mixed", 0))
     row("16 x 1024x1024 RGBA, qoi_compat=0", Uniform(sq, torch, dev, 16, 1024, 1024, 4, "mixed", 0))
+    # what `sqoaconv x.png y.qoi` makes (sqoaconv.c:84-90): the encoder cuts it into strips and hands the colour index from strip to
+    # strip (sqoa_strips.hip); the decoder's INDEX ops make every pixel depend on the values of all earlier ones: one workgroup
+    row("one 3840x2160 RGBA image alone, qoi_compat=1", Uniform(sq, torch, dev, 1, 3840, 2160, 4, "mixed", 0, qoi=1))
     # BASELINE.json configs[4] as rank 0 of 8 sees it: its LPT shard of the 65 536 suite-shaped images in one plan per direction
     from seqoia_amd import suite
 

@@ -35,6 +35,10 @@ struct sqoa_st_tables {
     void* d_jobs; void* d_ids; void* d_results;   // strip jobs, their id list (-1: skipped row), their result rows
     void* d_offsets;                // n_strips + 1 prefix sums of the strips' stream lengths
     void* d_ws; size_t ws_bytes;    // the strips' output slots
+    // QOI-compat images among them: the LAST n_images_qoi image rows / n_strips_qoi strip rows
+    int n_images_qoi, n_strips_qoi;
+    void* d_qtab;                   // per strip row 64 x 8 bytes: the strip's last writer per slot of the colour index
+    void* d_qtin;                   // per strip row 64 dwords: the colour index entering the strip
 };
 
 namespace sqoa {

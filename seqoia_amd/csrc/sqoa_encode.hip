@@ -437,7 +437,8 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,
-                                                        sqoa_hip_result* __restrict__ results) {
+                                                        sqoa_hip_result* __restrict__ results,
+                                                        const uint32_t* __restrict__ qtab_in) {   // QOI strip jobs: the colour index entering job i at [64 * i, 64 * i + 64); else null
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
     __shared__ __attribute__((aligned(16))) uint8_t s_pre[W][ENC_PRE];
     __shared__ unsigned long long s_run[2][W];
@@ -468,9 +469,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     gcptr8 src = (gcptr8)job.src;
     gptr8 dst = (gptr8)job.dst;
     // Strip jobs (sqoa_hip.h): a job may hold a stretch of an image's pixels only -- no header, no end marker, the pixel in front
-    // of src as the first pixel's predecessor.  SQOA-native only (the plan refuses them for QOI-compat: the colour index
-    // would have to cross the cut).
-    const uint32_t sflags = QOI ? 0u : job.reserved;
+    // of src as the first pixel's predecessor.  From callers SQOA-native only (the plan refuses them for QOI-compat: the colour
+    // index crosses the cut); the plan's own QOI-compat strips (sqoa_strips.hip) come with the index entering each of them.
+    const uint32_t sflags = job.reserved;
     const bool strip_last = !(sflags & SQOA_HIP_JOB_NOEND);   // the job ends the image: end marker, and a trailing run is the single 0xfd of seqoia.h:640-642
     const uint32_t hdr_len = (sflags & SQOA_HIP_JOB_NOHEADER) ? 0u : QOI ? kHeader : kHeader + 1;
     const uint32_t nsub = (N + ENC_SUB - 1) / ENC_SUB;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t h = qoi_hash(cur[s]);
                 if (ne && stamp[h] == (uint32_t)(s * 64 + lane + 1)) pub[h] = cur[s];
             }
-            uint32_t tin = 0;  // seqoia.h:518
+            uint32_t tin = qtab_in ? qtab_in[(size_t)jid * 64 + lane] : 0u;  // seqoia.h:518, or what the strips in front left
             if (j > 0) {
                 const uint32_t pp = ((j - 1) / W) & 1, pw = (j - 1) % W;
                 for (uint32_t spin = 0;; ++spin) {
@@ -1131,16 +1132,24 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
 // ---- launch -----------------------------------------------------------------------------
 
+extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
+    return sqoa_launch_encode_tab(d_jobs, d_ids, n, qoi, d_results, nullptr, stream);
+}
+
+// `d_qtab_in` (QOI-compat strip jobs only, else null): the colour index entering job i, 64 dwords at [64 * i]
+extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     // 8 waves per image, four images per CU: the kernel is VALU-issue bound (tools/ubench/valu_table.hip)
 #ifndef SQOA_ENC_W
 #define SQOA_ENC_W 8
 #endif
     constexpr int W = SQOA_ENC_W;
-    if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
-    else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results);
+    if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
+    else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1150,8 +1159,8 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (qoi) hipLaunchKernelGGL((encode_kernel<1, true>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results);
-    else hipLaunchKernelGGL((encode_kernel<1, false>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results);
+    if (qoi) hipLaunchKernelGGL((encode_kernel<1, true>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
+    else hipLaunchKernelGGL((encode_kernel<1, false>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -48,6 +48,16 @@ extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_
 #ifndef SQOA_ST_SOLO
 #define SQOA_ST_SOLO (385.0 * 1.25)
 #endif
+// QOI-compat images (the colour index enters every strip through two more small kernels, sqoa_strips.hip).  The QOI-compat
+// encoder is the slower kernel: alone an image runs at 0.755 Mpixel / ms, the chip at 290; cut into strips a full chip's worth of
+// images costs 1.83 x (tools/time_single_qoi.py, 1024 x 1024 images: one 0.069 against 1.33 ms, 16: 0.14 / 1.34, 64: 0.45 / 1.36,
+// 256: 1.64 / 1.37, 1024: 6.47 / 3.53 ms; one 3840 x 2160 image 0.138 against 10.4 ms).
+#ifndef SQOA_STQ_COST
+#define SQOA_STQ_COST 1.85
+#endif
+#ifndef SQOA_STQ_SOLO
+#define SQOA_STQ_SOLO 385.0
+#endif
 #ifndef SQOA_ST_MIN_PX
 #define SQOA_ST_MIN_PX 16384u      // pixels per strip, at least (32 sub-tiles: four per wave)
 #endif
@@ -94,7 +104,8 @@ struct sqoa_hip_plan {
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
-    sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // encode: the few large images cut into strips
+    sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};   // encode: the few large images cut into strips
+    int n_cut_sqoa = 0, n_cut_qoi = 0;   // how many at the front of the SQOA / QOI-compat id list they are
     size_t st_images_cap = 0, st_strips_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -256,7 +267,11 @@ int sqoa_hip_decode_route(const unsigned int* src_sizes, int n, int cus, int mod
 
 // The same choice for an encode plan's SQOA-native images: order[0 .. *n_strip_images) = the images cut into strips (largest
 // first; strips[k] = how many for order[k]), the rest one workgroup each.  `pixels[i]` = width * height.
+static int encode_route(const unsigned long long* pixels, int n, int cus, int mode, double st_cost, double st_solo, int* order, int* strips, int* n_strip_images);
 int sqoa_hip_encode_route(const unsigned long long* pixels, int n, int cus, int mode, int* order, int* strips, int* n_strip_images) {
+    return encode_route(pixels, n, cus, mode, SQOA_ST_COST, SQOA_ST_SOLO, order, strips, n_strip_images);
+}
+static int encode_route(const unsigned long long* pixels, int n, int cus, int mode, double st_cost, double st_solo, int* order, int* strips, int* n_strip_images) {
     if (!pixels || !order || !strips || !n_strip_images || n < 0 || cus <= 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_encode_route: bad arguments");
     std::vector<int> ids(n);
     for (int i = 0; i < n; ++i) ids[i] = i;
@@ -270,7 +285,7 @@ int sqoa_hip_encode_route(const unsigned long long* pixels, int n, int cus, int 
         for (size_t k = 0; k <= (size_t)n; ++k) {
             const double bk = k < (size_t)n ? (double)pixels[ids[k]] : 0.0;
             const double rest = all - head;
-            const double cost = SQOA_ST_COST * head + (SQOA_ST_SOLO * bk > rest ? SQOA_ST_SOLO * bk : rest);
+            const double cost = st_cost * head + (st_solo * bk > rest ? st_solo * bk : rest);
             if (mode > 0 || k == 0 || cost < best) { best = cost; k_best = k; head_best = head; }
             if (k == (size_t)n || pixels[ids[k]] < 2ull * SQOA_ST_MIN_PX || pixels[ids[k]] > 0xffffffffull) break;
             head += bk;
@@ -309,7 +324,8 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         }
     }
     // whatever fails below, the plan must not keep the previous fill's route tables beside the new id list
-    p->st.n_images = p->st.n_strips = 0;
+    p->st.n_images = p->st.n_strips = p->st.n_images_qoi = p->st.n_strips_qoi = 0;
+    p->n_cut_sqoa = p->n_cut_qoi = 0;
     p->dp.n_images = p->dp.n_wgs = 0;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
@@ -322,7 +338,8 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     typedef sqoa::st_strip st_strip_row;
     std::vector<st_image_row> st_images;
     std::vector<st_strip_row> st_strips;
-    size_t st_ws = 0;
+    size_t st_ws = 0, st_images_sqoa = 0, st_strips_sqoa = 0;   // (the QOI-compat images' rows lie behind the SQOA-native ones')
+    int n_cut_a = 0, n_cut_b = 0;
     if (p->kind == SQOA_HIP_ENCODE) {
         // largest image first (see sqoa_hip_decode_route), then boustrophedon; the QOI-compat list as it is
         auto npx = [&](int i) { return (unsigned long long)jobs[i].desc.width * jobs[i].desc.height; };
@@ -337,32 +354,43 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             snake(v, cut, cus);
             return (int)(v.size() - cut);
         };
-        p->n_sqoa_small = 0;
-        p->n_qoi_small = split_small(ids_b, 0);
-        if (!ids_a.empty()) {
-            // SQOA_HIP_STRIPS=0 / =1 in the environment: never / every image that is large enough (tests and measurements).  A
-            // caller that sends strip jobs of its own (sqoa_host.c) has done the cutting already.
-            const char* knob = getenv("SQOA_HIP_STRIPS");
-            int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
-            std::vector<unsigned long long> px(ids_a.size());
-            for (size_t k = 0; k < ids_a.size(); ++k) { px[k] = npx(ids_a[k]); if (jobs[ids_a[k]].reserved) mode = -1; }
-            std::vector<int> order(ids_a.size()), nst(ids_a.size());
+        // SQOA_HIP_STRIPS=0 / =1 in the environment: never / every image that is large enough (tests and measurements).  A
+        // caller that sends strip jobs of its own has done the cutting already.  The images cut come first in their list,
+        // SQOA-native ones first in the tables, QOI-compat ones behind them (sqoa_launch_encode_strips).
+        const char* knob = getenv("SQOA_HIP_STRIPS");
+        const int knob_mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
+        auto route_list = [&](std::vector<int>& ids, bool qoi, int* n_small) -> int {
+            *n_small = 0;
+            if (ids.empty()) return 0;
+            int mode = knob_mode;
+            std::vector<unsigned long long> px(ids.size());
+            for (size_t k = 0; k < ids.size(); ++k) { px[k] = npx(ids[k]); if (jobs[ids[k]].reserved) mode = -1; }
+            std::vector<int> order(ids.size()), nst(ids.size());
             int n_cut = 0;
-            int rc = sqoa_hip_encode_route(px.data(), (int)px.size(), cus, mode, order.data(), nst.data(), &n_cut);
-            if (rc) return rc;
-            std::vector<int> sorted(ids_a.size());
-            for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
-            ids_a.swap(sorted);
+            int rc = encode_route(px.data(), (int)px.size(), cus, mode, qoi ? SQOA_STQ_COST : SQOA_ST_COST, qoi ? SQOA_STQ_SOLO : SQOA_ST_SOLO,
+                                  order.data(), nst.data(), &n_cut);
+            if (rc) return -1;
+            std::vector<int> sorted(ids.size());
+            for (size_t k = 0; k < ids.size(); ++k) sorted[k] = ids[order[k]];
+            ids.swap(sorted);
             for (int k = 0; k < n_cut; ++k) {
-                const int i = ids_a[k];
+                const int i = ids[k];
                 const uint32_t ch = (jobs[i].desc.channels < 3 ? 1u : 3u) + ((jobs[i].desc.channels & 1) ? 0u : 1u);
                 const uint32_t first = (uint32_t)st_strips.size(), ns = (uint32_t)nst[k];
+                const uint32_t img = (uint32_t)st_images.size();
                 st_images.push_back({i, first, ns, (uint32_t)npx(i), (unsigned long long)st_ws});   // (.ws: offset, the base is added below)
-                for (uint32_t q = 0; q < ns; ++q) st_strips.push_back({(uint32_t)k, q});
+                for (uint32_t q = 0; q < ns; ++q) st_strips.push_back({img, q});
                 st_ws += (((size_t)npx(i) * (ch + 1) + 255) & ~(size_t)255) + (size_t)ns * 512 + 512;
             }
-            p->n_sqoa_small = split_small(ids_a, (size_t)n_cut);
-        }
+            *n_small = split_small(ids, (size_t)n_cut);
+            return n_cut;
+        };
+        const int cut_a = route_list(ids_a, false, &p->n_sqoa_small);
+        if (cut_a < 0) return SQOA_HIP_EINVAL;
+        st_images_sqoa = st_images.size(); st_strips_sqoa = st_strips.size();
+        const int cut_b = route_list(ids_b, true, &p->n_qoi_small);
+        if (cut_b < 0) return SQOA_HIP_EINVAL;
+        n_cut_a = cut_a; n_cut_b = cut_b;
     } else if (!ids_a.empty()) {
         unsigned long long bytes = 0;
         std::vector<unsigned int> sizes(ids_a.size());
@@ -415,14 +443,19 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     };
     p->st.n_images = (int)st_images.size();
     p->st.n_strips = (int)st_strips.size();
+    p->st.n_images_qoi = (int)(st_images.size() - st_images_sqoa);
+    p->st.n_strips_qoi = (int)(st_strips.size() - st_strips_sqoa);
+    p->n_cut_sqoa = n_cut_a;
+    p->n_cut_qoi = n_cut_b;
     if (!st_images.empty()) {
         const size_t ni = st_images.size(), ns = st_strips.size();
         e = grow(&p->st.d_images, &p->st_images_cap, ni, sizeof(st_image_row));
         if (e == hipSuccess && ns > p->st_strips_cap) {   // the per-strip tables share one capacity
-            void** tabs[6] = {&p->st.d_strips, &p->st.d_cuts, &p->st.d_jobs, &p->st.d_ids, &p->st.d_results, &p->st.d_offsets};
-            const size_t row[6] = {sizeof(st_strip_row), sizeof(uint32_t), sizeof(sqoa_hip_job), sizeof(int), sizeof(sqoa_hip_result), sizeof(unsigned long long)};
+            void** tabs[8] = {&p->st.d_strips, &p->st.d_cuts, &p->st.d_jobs, &p->st.d_ids, &p->st.d_results, &p->st.d_offsets, &p->st.d_qtab, &p->st.d_qtin};
+            const size_t row[8] = {sizeof(st_strip_row), sizeof(uint32_t), sizeof(sqoa_hip_job), sizeof(int), sizeof(sqoa_hip_result), sizeof(unsigned long long),
+                                   64 * sizeof(unsigned long long), 64 * sizeof(uint32_t)};
             p->st_strips_cap = 0;
-            for (int t = 0; t < 6 && e == hipSuccess; ++t) {
+            for (int t = 0; t < 8 && e == hipSuccess; ++t) {
                 if (*tabs[t]) { hipFree(*tabs[t]); *tabs[t] = nullptr; }
                 e = hipMalloc(tabs[t], (ns + 1) * row[t]);
             }
@@ -433,14 +466,16 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             // no memory for the strips' workspace (5 bytes per pixel of the images cut): not an error -- the images stay where they
             // are in the id list, its largest entries, and get a workgroup each like the rest
             (void)hipGetLastError();
-            p->st.n_images = p->st.n_strips = 0;
+            p->st.n_images = p->st.n_strips = p->st.n_images_qoi = p->st.n_strips_qoi = 0;
+            p->n_cut_sqoa = p->n_cut_qoi = 0;
             st_images.clear();
         }
         if (st_images.empty()) goto strips_done;
         for (auto& r : st_images) r.ws += (unsigned long long)(uintptr_t)p->st.d_ws;
         if ((e = hipMemcpy(p->st.d_images, st_images.data(), sizeof(st_image_row) * ni, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemcpy(p->st.d_strips, st_strips.data(), sizeof(st_strip_row) * ns, hipMemcpyHostToDevice)) != hipSuccess) {
-            p->st.n_images = p->st.n_strips = 0;
+            p->st.n_images = p->st.n_strips = p->st.n_images_qoi = p->st.n_strips_qoi = 0;
+            p->n_cut_sqoa = p->n_cut_qoi = 0;
             return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the strip encode, upload", e);
         }
     }
@@ -507,7 +542,7 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->d_results) hipFree(p->d_results);
     if (p->d_init) hipFree(p->d_init);
     if (p->d_ids) hipFree(p->d_ids);
-    for (void* d : {p->st.d_images, p->st.d_strips, p->st.d_cuts, p->st.d_jobs, p->st.d_ids, p->st.d_results, p->st.d_offsets, p->st.d_ws})
+    for (void* d : {p->st.d_images, p->st.d_strips, p->st.d_cuts, p->st.d_jobs, p->st.d_ids, p->st.d_results, p->st.d_offsets, p->st.d_ws, p->st.d_qtab, p->st.d_qtin})
         if (d) hipFree(d);
     if (p->dp.d_images) hipFree(p->dp.d_images);
     if (p->dp.d_wgs) hipFree(p->dp.d_wgs);
@@ -525,10 +560,12 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
     if (p->kind == SQOA_HIP_ENCODE) {
         HIP_TRY(sqoa_launch_encode_strips(p->d_jobs, p->d_results, &p->st, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->st.n_images, p->n_sqoa - p->st.n_images - p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, p->d_ids + p->n_sqoa - p->n_sqoa_small, p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, p->d_ids + p->n_sqoa, p->n_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, p->d_ids + p->n_sqoa + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+        // each id list: [images cut into strips (above) | one workgroup each | many small ones, one wave each]
+        const int* ida = p->d_ids; const int* idb = p->d_ids + p->n_sqoa;
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, ida + p->n_cut_sqoa, p->n_sqoa - p->n_cut_sqoa - p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, ida + p->n_sqoa - p->n_sqoa_small, p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
         HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }

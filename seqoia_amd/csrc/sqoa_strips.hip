@@ -13,6 +13,16 @@
 //   encode_kernel      over the strip jobs;
 //   strip_pack_kernel  one workgroup per strip: its stream goes behind the image's header (seqoia.h:497-514) and the streams
 //                      of the strips in front of it, at the image's own dst; the first one writes header and result row.
+//
+// QOI-compat images (qoi_compat = 1) carry one more piece of state across a cut: the 64-entry colour index (seqoia.h:563-582).
+// It only ever holds the LAST non-run pixel that hashed to each slot (a hit leaves the slot as it is, a miss overwrites it,
+// seqoia.h:566-571; run pixels never touch it, seqoia.h:544-550), so a strip's effect on it is "overwrite the slots I wrote"
+// whatever it held before -- and that composes in strip order.  Two more small kernels in front of the encoder:
+//
+//   strip_qtab_kernel  one workgroup per strip: the last non-run pixel per slot inside the strip (ds_max_u64 of position | value);
+//   strip_qscan_kernel one wave per image: walks the strips in order, writes the index entering each (64 dwords per strip).
+//
+// encode_kernel<8, true> then starts every strip from its entering index instead of from zeros (seqoia.h:518).
 #include "sqoa_common.h"
 
 namespace sqoa {
@@ -79,6 +89,55 @@ __global__ __launch_bounds__(64) void strip_job_kernel(const sqoa_hip_job* __res
     }
 }
 
+// QOI-compat strips: per slot of the colour index, the last pixel of the strip that differs from its predecessor and hashes to
+// the slot, as (pixel position in the strip + 1) << 32 | value; 0 = the strip does not write the slot.  One workgroup per strip row.
+__global__ __launch_bounds__(256) void strip_qtab_kernel(const sqoa_hip_job* __restrict__ sjobs, const int* __restrict__ sids, uint32_t row0,
+                                                         unsigned long long* __restrict__ qtab) {
+    __shared__ unsigned long long s_last[64];
+    const uint32_t row = row0 + blockIdx.x;
+    if (threadIdx.x < 64) s_last[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (sids[row] >= 0) {
+        const sqoa_hip_job job = sjobs[row];
+        const int ch = st_stride(job.desc);
+        gcptr8 src = (gcptr8)job.src;
+        const uint32_t n = job.desc.width * job.desc.height;
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
+            const uint32_t px = load_px(src, p, ch);
+            // the strip's first pixel: its predecessor is the pixel in front of the strip, or (0,0,0,255) at the image's start (seqoia.h:521-525)
+            const uint32_t pv = p ? load_px(src, p - 1, ch) : (job.reserved & SQOA_HIP_JOB_PREV) ? load_px(src - ch, 0, ch) : kPxInit;
+            if (px != pv) atomicMax(&s_last[qoi_hash(px)], (unsigned long long)(p + 1u) << 32 | px);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) qtab[(size_t)row * 64 + threadIdx.x] = s_last[threadIdx.x];
+}
+
+// The colour index entering every strip of an image: the strips' tables composed by overwrite, in strip order, from all zeros
+// (seqoia.h:518).  One wave per image, lane = slot; the loads of the strips ahead are independent of the chain.
+__global__ __launch_bounds__(64) void strip_qscan_kernel(const st_image* __restrict__ images, uint32_t img0, const unsigned long long* __restrict__ qtab,
+                                                         uint32_t* __restrict__ qtin) {
+    const st_image im = images[img0 + blockIdx.x];
+    const int lane = lane_id();
+    uint32_t t = 0;
+    uint32_t k = 0;
+    for (; k + 4 <= im.nstrips; k += 4) {
+        unsigned long long e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = qtab[(size_t)(im.first + k + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qtin[(size_t)(im.first + k + u) * 64 + lane] = t;
+            if (e[u] >> 32) t = (uint32_t)e[u];
+        }
+    }
+    for (; k < im.nstrips; ++k) {
+        const unsigned long long e = qtab[(size_t)(im.first + k) * 64 + lane];
+        qtin[(size_t)(im.first + k) * 64 + lane] = t;
+        if (e >> 32) t = (uint32_t)e;
+    }
+}
+
 // `offsets`: exclusive prefix sums of the strip rows' stream lengths (pack_offsets_kernel over the strips' result rows)
 __global__ __launch_bounds__(256) void strip_pack_kernel(const sqoa_hip_job* __restrict__ jobs, const st_image* __restrict__ images,
                                                          const st_strip* __restrict__ strips, const sqoa_hip_job* __restrict__ sjobs,
@@ -89,7 +148,8 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(const sqoa_hip_job* __r
     const sqoa_hip_job job = jobs[im.jid];
     const uint32_t row = im.first + me.k;
     gptr8 dst = (gptr8)job.dst;
-    constexpr uint32_t kHead = kHeader + 1;   // header + start byte (seqoia.h:497-514)
+    const bool qoi = job.desc.qoi_compat != 0;
+    const uint32_t kHead = qoi ? kHeader : kHeader + 1;   // header [+ start byte, SQOA] (seqoia.h:497-514)
     if (me.k == 0) {
         __shared__ int s_bad;
         if (threadIdx.x == 0) s_bad = 0;
@@ -98,7 +158,7 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(const sqoa_hip_job* __r
             if (sres[im.first + k].status != SQOA_HIP_ST_OK) s_bad = 1;
         __syncthreads();
         if (threadIdx.x < kHead) {
-            const uint32_t t = threadIdx.x, word = t < 4 ? 0x53716f61u : t < 8 ? job.desc.width : job.desc.height;
+            const uint32_t t = threadIdx.x, word = t < 4 ? (qoi ? 0x716f6966u : 0x53716f61u) : t < 8 ? job.desc.width : job.desc.height;
             dst[t] = t < 12 ? (uint8_t)(word >> (24 - 8 * (t & 3))) : t == 12 ? (uint8_t)st_stride(job.desc) : t == 13 ? job.desc.colorspace : (uint8_t)0x31;
         }
         if (threadIdx.x == 0) {
@@ -122,9 +182,11 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(const sqoa_hip_job* __r
 
 }  // namespace sqoa
 
-extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi, sqoa_hip_result* d_results,
+                                             const uint32_t* d_qtab_in, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_pack_offsets(const sqoa_hip_result* d_res, int n, unsigned long long* d_offsets, hipStream_t stream);
 
+// The images of the tables: SQOA-native ones first (strip rows [0, n_strips - n_strips_qoi)), QOI-compat ones behind them.
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream) {
     using namespace sqoa;
     if (!st || st->n_images <= 0 || st->n_strips <= 0) return hipSuccess;
@@ -132,14 +194,21 @@ extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa
     const st_strip* ss = (const st_strip*)st->d_strips;
     sqoa_hip_job* sjobs = (sqoa_hip_job*)st->d_jobs;
     sqoa_hip_result* sres = (sqoa_hip_result*)st->d_results;
+    const int* sids = (const int*)st->d_ids;
+    const int ns_q = st->n_strips_qoi, ns_s = st->n_strips - ns_q, ni_q = st->n_images_qoi, ni_s = st->n_images - ni_q;
     hipLaunchKernelGGL(strip_cut_kernel, dim3(st->n_strips), dim3(64), 0, stream, d_jobs, im, ss, (uint32_t*)st->d_cuts);
     hipLaunchKernelGGL(strip_job_kernel, dim3(st->n_images), dim3(64), 0, stream, d_jobs, im, (const uint32_t*)st->d_cuts, sjobs, (int*)st->d_ids, sres);
-    hipError_t e = sqoa_launch_encode(sjobs, (const int*)st->d_ids, st->n_strips, 0, sres, stream);
+    hipError_t e = sqoa_launch_encode_tab(sjobs, sids, ns_s, 0, sres, nullptr, stream);
     if (e != hipSuccess) return e;
+    if (ns_q > 0) {
+        hipLaunchKernelGGL(strip_qtab_kernel, dim3(ns_q), dim3(256), 0, stream, sjobs, sids, (uint32_t)ns_s, (unsigned long long*)st->d_qtab);
+        hipLaunchKernelGGL(strip_qscan_kernel, dim3(ni_q), dim3(64), 0, stream, im, (uint32_t)ni_s, (const unsigned long long*)st->d_qtab, (uint32_t*)st->d_qtin);
+        // (the kernel indexes the entering tables by job id = strip row)
+        e = sqoa_launch_encode_tab(sjobs, sids + ns_s, ns_q, 1, sres, (const uint32_t*)st->d_qtin, stream);
+        if (e != hipSuccess) return e;
+    }
     e = sqoa_launch_pack_offsets(sres, st->n_strips, (unsigned long long*)st->d_offsets, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(strip_pack_kernel, dim3(st->n_strips), dim3(256), 0, stream, d_jobs, im, ss, sjobs, sres, (const unsigned long long*)st->d_offsets, d_results);
     return hipGetLastError();
 }
-
-

@@ -614,3 +614,71 @@ def test_many_small_images_get_one_wave_each(sq, orc, mode):
     for k, (w, h, ch, _) in enumerate(shapes):
         assert got[k] == o.encode(raws[k], w, h, ch, mode), (k, w, h, ch)
     plan.close()
+
+
+@pytest.mark.parametrize("knob", ["1", ""])
+def test_qoi_compat_images_are_cut_into_strips_with_the_colour_index_handed_on(sq, orc, monkeypatch, knob):
+    """QOI-compat images take the strip route too (sqoa_strips.hip): the 64-entry colour index (seqoia.h:563-582) crosses every
+    cut -- per strip the last non-run pixel per slot, composed by overwrite in strip order, each strip encoded from the index
+    entering it.  Content that lives off the index (few colours recurring across the whole image, so that most ops are
+    QOI_OP_INDEX hits on pixels written many strips earlier), long runs across the nominal cuts (62-pixel run chunks), RGBA
+    and RGB, next to SQOA-native images in the same plan.  Byte identity with the reference, and with the one-workgroup route."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(79)
+    w, h = 640, 480
+    cases = []
+    for ch in (4, 3):
+        pal = rng.integers(0, 256, size=(23, ch), dtype=np.uint8)                      # 23 colours, re-used everywhere: INDEX hits across strips
+        idx = rng.integers(0, 23, size=w * h)
+        px = pal[idx]
+        for k in range(1, 18):
+            a = w * h * k // 18 - int(rng.integers(0, 300))
+            px[a:a + int(rng.choice([3, 61, 62, 63, 124, 125, 1500, 40000]))] = px[a]
+        cases.append((f"palette_ch{ch}", px.reshape(-1).copy(), ch, 1))
+        cases.append((f"noise_ch{ch}", rng.integers(0, 256, size=w * h * ch, dtype=np.uint8), ch, 1))
+    cases.append(("one_colour", np.full(w * h * 4, 37, dtype=np.uint8), 4, 1))
+    cases.append(("default_pixel", np.tile(np.array([0, 0, 0, 255], dtype=np.uint8), w * h), 4, 1))
+    cases.append(("zero_pixel", np.zeros(w * h * 4, dtype=np.uint8), 4, 1))            # (0,0,0,0) hashes to slot 0, whose initial content it equals
+    cases.append(("mixed", orc.synth(w, h, 4, "mixed", 11, 0), 4, 1))
+    cases.append(("icon", orc.synth(w, h, 3, "icon", 11, 1), 3, 1))
+    cases.append(("sqoa_neighbour", orc.synth(w, h, 4, "mixed", 11, 2), 4, 0))          # an SQOA-native image in the same plan
+    cases.append(("sqoa_icon_neighbour", orc.synth(w, h, 3, "icon", 11, 3), 3, 0))
+    wants = [o.encode(px, w, h, ch, mode) for name, px, ch, mode in cases]
+    for setting in (knob, "0"):
+        monkeypatch.setenv("SQOA_HIP_STRIPS", setting)
+        plan = sq.EncodeList([(torch.from_numpy(px).cuda(), sq.Desc(w, h, ch, 0, mode)) for name, px, ch, mode in cases])
+        for _ in range(2):
+            plan.launch()
+        res = plan.results()
+        got = plan.streams()
+        assert (res["status"] == 0).all(), (setting, res["status"].tolist())
+        for k, (name, px, ch, mode) in enumerate(cases):
+            assert got[k] == wants[k], (name, "strips" if setting != "0" else "one workgroup")
+        plan.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("ch", [3, 4])
+def test_large_single_image(sq, orc, mode, ch):
+    """What `sqoaconv x.png y.qoi` / `y.sqoa` produces (sqoaconv.c:84-90): ONE screenshot-sized image, through the legacy call and
+    as a plan of one job -- both wire formats take the whole chip (strips; QOI-compat with the colour index handed on)."""
+    import torch
+
+    w, h = 3840, 2160
+    t = torch.empty((1, h, w, ch), dtype=torch.uint8, device="cuda")
+    sq.synth(t, "mixed", seed=4, img0=7)
+    px = t.cpu().numpy().reshape(-1)
+    want = orc.best().encode(px, w, h, ch, mode)
+    enc = sq.EncodePlan(t, qoi_compat=mode)
+    enc.launch()
+    res = enc.results()
+    assert res["status"][0] == 0 and int(res["len"][0]) == len(want)
+    assert enc.streams()[0] == want
+    dec = sq.DecodePlan(enc.out, res["len"], w, h, ch)
+    dec.launch()
+    assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, t)
+    dec.close()
+    enc.close()
+    assert sq.encode(px, sq.Desc(w, h, ch, 0, mode)) == want
