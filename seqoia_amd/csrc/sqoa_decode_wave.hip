@@ -95,7 +95,10 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 // What the LDS chain carries, per workgroup (DP_CHUNKS_PER_WG chunks), in HBM: the composite of its chunks' transition functions,
 // pixel counts and transforms (written by passes 1 and 2), and what enters its first chunk (written by the two scans).
 struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };
-constexpr uint32_t DP_CHUNKS_PER_WG_MIN = 16, DP_CHUNKS_PER_WG_MAX = 64;   // chunks per workgroup of a pass: the plan picks (sqoa_dp_layout)
+#ifndef SQOA_DP_PER_MIN
+#define SQOA_DP_PER_MIN 8   /* one chunk per wave: a lone 1 Mpixel stream 0.040 -> 0.036 ms; from 8 streams on no difference */
+#endif
+constexpr uint32_t DP_CHUNKS_PER_WG_MIN = SQOA_DP_PER_MIN, DP_CHUNKS_PER_WG_MAX = 64;   // chunks per workgroup of a pass: the plan picks (sqoa_dp_layout)
 
 // The two scans between the passes: one workgroup of 1024 threads per image, every thread a contiguous run of the image's
 // table rows -- its run composed serially (independent loads), one scan over the 1024 run totals (DPP inside the waves, LDS

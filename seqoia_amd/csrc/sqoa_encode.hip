@@ -35,7 +35,11 @@ constexpr int ENC_PRE = ENC_SUB * 4;   // landing buffer of the next sub-tile's 
 constexpr uint32_t SPIN_MAX = 1u << 22;
 
 struct EncState {
-    uint32_t bad;  // chain wait timed out (never expected)
+    uint32_t bad;   // chain wait timed out (never expected)
+    uint32_t eager; // a strip job: poll the chain words at short intervals.  A full batch (four images per CU) wants long ones --
+                    // a polling wave spends scalar issue slots the other images' waves need (2.13 -> 2.09 ms at 8 x 64 cycles
+                    // against 1 x 64) -- but a strip of a lone image has the CU to itself and its 32 sub-tiles are one serial
+                    // chain of position hand-overs: at 512-cycle polls that chain, not the work, was half of the kernel's 22 us
 };
 
 // Wait until the 8-byte LDS word carries `tag` in its high half; returns the low half.
@@ -46,7 +50,7 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t hi = bcast_first((uint32_t)(v >> 32));
         if (hi == tag) return bcast_first((uint32_t)v);
-        __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
+        if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
     }
     st.bad = 1;
     return 0;
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #else
 #define PHASE(k) do { } while (0)
 #endif
-    EncState st{0};
+    EncState st{0, bcast_first(job.reserved != 0u ? 1u : 0u)};
 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
     bool cur_raw3 = false;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     const uint32_t t = __hip_atomic_load(&s_tabtag[pp][pw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (bcast_first(t) == j) break;
                     if (spin >= SPIN_MAX) { st.bad = 1; break; }
-                    __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
+                    if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
                 }
                 tin = s_tabpub[pp][pw % QW][lane];
             }

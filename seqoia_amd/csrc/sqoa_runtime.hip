@@ -58,11 +58,19 @@ extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_
 #ifndef SQOA_STQ_SOLO
 #define SQOA_STQ_SOLO 385.0
 #endif
+// Strips: 16 384 pixels each (32 sub-tiles, four per wave) when that fills the chip; a lone image gets at least one strip per
+// compute unit, down to 4096 pixels (8 sub-tiles: one per wave) -- a strip's sub-tiles are one serial chain of position
+// hand-overs, and the other CUs are idle anyway (one 1024 x 1024 image: 64 strips 0.036 ms, 256 strips 0.024 ms); never more
+// than SQOA_ST_WGS strips per launch (two rounds of workgroups on the chip: a 3840 x 2160 image in 2025 strips took 0.071 ms,
+// in 506 strips 0.056 ms -- every strip costs a cut search, a prologue and a piece of the pack).
 #ifndef SQOA_ST_MIN_PX
-#define SQOA_ST_MIN_PX 16384u      // pixels per strip, at least (32 sub-tiles: four per wave)
+#define SQOA_ST_MIN_PX 4096u
+#endif
+#ifndef SQOA_ST_PX
+#define SQOA_ST_PX 16384u
 #endif
 #ifndef SQOA_ST_WGS
-#define SQOA_ST_WGS 2048u          // strips aimed at per launch: two rounds of workgroups on the chip
+#define SQOA_ST_WGS 2048u
 #endif
 // Encode: images of at most SQOA_ENC_SMALL_PX pixels get one wave each when a plan holds at least SQOA_ENC_SMALL_MIN of them
 // (sqoa_encode.hip, sqoa_launch_encode_small; a few small images are done sooner by eight waves each).
@@ -287,12 +295,15 @@ static int encode_route(const unsigned long long* pixels, int n, int cus, int mo
             const double rest = all - head;
             const double cost = st_cost * head + (st_solo * bk > rest ? st_solo * bk : rest);
             if (mode > 0 || k == 0 || cost < best) { best = cost; k_best = k; head_best = head; }
-            if (k == (size_t)n || pixels[ids[k]] < 2ull * SQOA_ST_MIN_PX || pixels[ids[k]] > 0xffffffffull) break;
+            if (k == (size_t)n || pixels[ids[k]] < 2ull * SQOA_ST_PX || pixels[ids[k]] > 0xffffffffull) break;
             head += bk;
         }
     }
-    // pixels per strip: SQOA_ST_WGS strips over all the images cut, SQOA_ST_MIN_PX at least
-    double per = head_best / SQOA_ST_WGS;
+    // pixels per strip (see SQOA_ST_PX above)
+    double want = head_best / SQOA_ST_PX;
+    if (want < cus) want = cus;
+    if (want > SQOA_ST_WGS) want = SQOA_ST_WGS;
+    double per = head_best / want;
     if (per < SQOA_ST_MIN_PX) per = SQOA_ST_MIN_PX;
     for (size_t k = 0; k < (size_t)n; ++k) {
         double s = k < k_best ? (double)pixels[ids[k]] / per : 0.0;

@@ -138,8 +138,10 @@ def test_encode_route_cuts_the_images_that_would_outlast_the_batch():
     mp = 1 << 20
     order, strips, k = route([mp] * 1024)                      # the headline batch: one workgroup per image
     assert k == 0 and sorted(order) == list(range(1024)) and not any(strips)
-    order, strips, k = route([mp])                             # a lone image: 64 strips of 16 384 pixels
-    assert (order, k) == ([0], 1) and strips == [64]
+    order, strips, k = route([mp])                             # a lone image: a strip per compute unit, 256 of 4096 pixels
+    assert (order, k) == ([0], 1) and strips == [256]
+    order, strips, k = route([mp] * 16)                        # enough images to fill the chip: strips of 16 384 pixels
+    assert k == 16 and strips == [64] * 16
     order, strips, k = route([3840 * 2160])                    # a lone screenshot: about 2048 strips / 4 rounds... at least a few hundred
     assert k == 1 and 400 <= strips[0] <= 2048
     order, strips, k = route([64 * 64] * 100)                  # icons: too small to cut
