@@ -118,7 +118,13 @@ SQOA_DEV NbrPx sload_px(unsigned long long addr, int ch, uint32_t orv) {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
-SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane) {
+SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) {
+    // The lane number, recomputed here and opaque to the compiler: with the caller's `lane` the per-lane LDS addresses below are
+    // loop invariants, which at 64 VGPRs get SPILLED -- and every reload is a scratch_load + s_waitcnt vmcnt(0) in the middle of
+    // the flush, i.e. a wait for the 16-byte stores issued just before it (the flush's pieces went out one store latency apart).
+    (void)lane_unused;
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 #if defined(SQOA_ENC_FLUSH_ALIGNED)
     uint32_t a = (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u;
     if (a > T) a = T;
