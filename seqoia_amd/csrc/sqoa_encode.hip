@@ -636,6 +636,11 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         constexpr bool swar = SW;
         SwarGroup grp[ENC_S / 4];
         // a sub-tile that is one solid run (flat areas of icons / screenshots) needs no per-pixel work at all
+        // (SQOA-native only.  Run pixels never touch the colour index -- seqoia.h:544-550 come before :563 -- so the same shortcut is
+        // right for QOI-compat sub-tiles [0xfd at every multiple of 62: floor((c_in + 512) / 62) - floor(c_in / 62) of them, then the
+        // flush]; built and measured in round 3: icons 4096 x 512 x 512 RGB unchanged at 4.81 ms (a sub-tile is a whole row of 16
+        // tiles there, never one run), the headline batch 3.59 -> 3.69 ms for the test alone.  The same for skipping the index
+        // probe of rows that are all run: 3.59 -> 4.01 ms, icons 4.81 -> 4.98 ms.)
         bool flat = false;
         if (swar && !QOI) {
             uint32_t dif = 0;
