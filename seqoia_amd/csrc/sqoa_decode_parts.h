@@ -60,6 +60,10 @@ typedef const __attribute__((address_space(3))) u32x4* lcptr128;
 
 // bytewise (mod 256) add / sub of four packed channels
 SQOA_DEV uint32_t add8(uint32_t a, uint32_t b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
+// The same with the two SWAR constants handed in, for callers that keep them in VGPRs: as literals the compiler parks them in SGPRs,
+// and a three-operand instruction with an SGPR operand is slow-class -- two of add8's five instructions.
+struct HL { uint32_t H, L; };
+SQOA_DEV uint32_t add8(uint32_t a, uint32_t b, HL k) { return ((a & k.L) + (b & k.L)) ^ ((a ^ b) & k.H); }
 SQOA_DEV uint32_t sub8(uint32_t a, uint32_t b) { return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u); }
 
 // one colour pixel at pixel index P; OC = 3 or 4 output channels, 40 = four channels at an address that is not dword-aligned
@@ -85,5 +89,7 @@ struct Xf { uint32_t v, abs; };
 // (b.v holds the value itself in b's absolute channels and a delta elsewhere, so masking a's side first is enough)
 SQOA_DEV Xf xf_then(Xf a, Xf b) { return Xf{add8(a.v & ~b.abs, b.v), a.abs | b.abs}; }
 SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px) { return add8(px & ~t.abs, t.v); }
+SQOA_DEV Xf xf_then(Xf a, Xf b, HL k) { return Xf{add8(a.v & ~b.abs, b.v, k), a.abs | b.abs}; }
+SQOA_DEV uint32_t xf_apply(Xf t, uint32_t px, HL k) { return add8(px & ~t.abs, t.v, k); }
 
 }  // namespace sqoa

@@ -71,6 +71,23 @@ SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lan
 }
 
 template <int CTRL, int ROWMASK>
+SQOA_DEV Xf xf_scan_step(Xf T, HL k) {
+    Xf P;
+    constexpr bool BC = ROWMASK == 0xf;
+    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, BC);
+    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, BC);
+    return xf_then(P, T, k);
+}
+SQOA_DEV Xf wave_xf_scan(Xf T, HL k) {
+    T = xf_scan_step<DPP_ROW_SHR + 1, 0xf>(T, k);
+    T = xf_scan_step<DPP_ROW_SHR + 2, 0xf>(T, k);
+    T = xf_scan_step<DPP_ROW_SHR + 4, 0xf>(T, k);
+    T = xf_scan_step<DPP_ROW_SHR + 8, 0xf>(T, k);
+    T = xf_scan_step<DPP_ROW_BCAST15, 0xa>(T, k);
+    T = xf_scan_step<DPP_ROW_BCAST31, 0xc>(T, k);
+    return T;
+}
+template <int CTRL, int ROWMASK>
 SQOA_DEV Xf xf_scan_step(Xf T) {
     Xf P;  // the transform of the lanes below, identity (all zero) where there is none
     // (all rows enabled: a source lane out of range reads as zero with bound_ctrl, no v_mov of the zero in front of the DPP move)
@@ -323,6 +340,14 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #endif
     uint32_t* lds = s_bytes[w];
     uint32_t stg[DEC_NLD];
+#ifdef SQOA_DEC_HL_VGPR   // A/B builds: 5 VGPR spills instead of 1 at the 64-register cliff, 3.40 -> 3.45 ms -- off
+    HL hl;   // the SWAR constants of the packed-byte adds, in VGPRs (see add8 in sqoa_decode_parts.h)
+    asm volatile("v_mov_b32 %0, 0x80808080" : "=v"(hl.H));
+    asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(hl.L));
+#define HLARG , hl
+#else
+#define HLARG
+#endif
     // straight-line when the whole staging window lies inside the stream (all but the last chunks): three
     // loads in flight, no wait until the next iteration stages them
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[DEC_NLD]) {
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
             const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;                         // LUMA, seqoia.h:761-769
             const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
-            T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm});
+            T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm} HLARG);
             val[i] = T.v;
             meta[i] = cl | cnt << 13;
             amask[i] = T.abs;
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         // ---- 3. wave scans: pixel positions and pixel transforms of the lanes below ------------
         const uint32_t cinc = wave_incl_scan(cl);
         const uint32_t ctot = bcast_lane(cinc, 63);
-        const Xf Ti = wave_xf_scan(T);
+        const Xf Ti = wave_xf_scan(T HLARG);
         const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
         const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
 
@@ -520,7 +545,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         }
 
         if (pos_in < N) {
-            const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
+            const uint32_t lane_px = xf_apply(Tx, px_in HLARG);       // pixel entering my lane
             const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
             const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
             if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
@@ -550,7 +575,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 for (int i = 0; i < DEC_LB; ++i) {
                     if ((uint32_t)i >= iters) break;
                     const uint32_t m = meta[i], am = amask[i];
-                    const uint32_t v = add8(lane_px & ~am, val[i]);
+                    const uint32_t v = add8(lane_px & ~am, val[i] HLARG);
                     const uint32_t off = lane_off + ((m & 0x1fffu) << 2);
                     asm volatile(
                         "v_cmpx_lt_u32_e32 vcc, 0x1fff, %[m]\n\t"          // cnt >= 1

@@ -174,6 +174,46 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) 
 #endif
 }
 
+// 2 KB (1.5 KB: `half_second`, 3-byte pixels) of a sub-tile's pixels from global memory straight into the wave's landing buffer in
+// LDS: two global_load_lds_dwordx4, lane l -> bytes [16 l, 16 l + 16) and [1024 + 16 l, ...).  Hand-written, for two reasons.  (1)
+// Issued through the builtin, the compiler knows that something writes LDS asynchronously and puts an s_waitcnt vmcnt(0) in front of
+// EVERY later LDS access it cannot prove disjoint from the landing buffer -- the chain posts and polls, the run table, the staging
+// ORs: the "prefetch" of the next sub-tile was waited for at the first LDS instruction behind it, a full memory latency on every
+// sub-tile.  The one place that reads the landing buffer (take / take8) does its own s_waitcnt vmcnt(0).  (2) The per-lane source
+// address was a loop invariant that got spilled; its reload (scratch_load + vmcnt(0)) in front of the loads drained the stores of the
+// flush just before.  Here the address is an SGPR base + 16 * lane, the lane number recomputed on the spot.
+SQOA_DEV void lds_dma(unsigned long long gaddr, uint8_t* lds_dst, bool half_second) {
+    const uint32_t lds_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_dst);
+    uint32_t keep, off;
+    if (!half_second) {
+        asm volatile(
+            "v_mbcnt_lo_u32_b32 %[off], -1, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[off], -1, %[off]\n\t"
+            "v_lshlrev_b32 %[off], 4, %[off]\n\t"
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[lds]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"                       // (every earlier read of the landing buffer has returned)
+            "global_load_lds_dwordx4 %[off], %[base]\n\t"
+            "global_load_lds_dwordx4 %[off], %[base] offset:1024\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep), [off] "=&v"(off) : [base] "s"(gaddr), [lds] "s"(lds_addr) : "memory");
+    } else {
+        asm volatile(
+            "v_mbcnt_lo_u32_b32 %[off], -1, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[off], -1, %[off]\n\t"
+            "v_lshlrev_b32 %[off], 4, %[off]\n\t"
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[lds]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "global_load_lds_dwordx4 %[off], %[base]\n\t"
+            "s_mov_b32 exec_hi, 0\n\t"                        // lanes 0..31: bytes [1024, 1536)
+            "global_load_lds_dwordx4 %[off], %[base] offset:1024\n\t"
+            "s_mov_b32 exec_hi, -1\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep), [off] "=&v"(off) : [base] "s"(gaddr), [lds] "s"(lds_addr) : "memory");
+    }
+}
+
 // ---- SWAR main pass: four 64-pixel rows at a time, one byte lane per row -------------------------------
 // gfx950 issues add / sub / logic / right-shift / bitop3 on VGPR or literal operands at 1.7x the rate of every other
 // VALU instruction (tools/ubench/valu_table.hip), and the per-pixel op decision (seqoia.h:584-635) is all 8-bit arithmetic.
@@ -545,9 +585,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         const bool interior = K ? true : (base > 0 && base + ENC_SUB < N);
         raw3 = false;
         if (interior && (K == 2 || ch == 4)) {
+#ifdef SQOA_ENC_BUILTIN_DMA
             gcptr8 p = src + (size_t)base * 4;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
+#else
+            lds_dma(job.src + (unsigned long long)base * 4, pre, false);
+#endif
             if ((job.src & 3ull) == 0) {  // dword-aligned pixels: one scalar load each
                 pb = NbrPx{*(kcptr32)(job.src + (unsigned long long)base * 4 - 4), 0u, 0u, 0u};
                 pa = NbrPx{*(kcptr32)(job.src + (unsigned long long)base * 4 + ENC_SUB * 4), 0u, 0u, 0u};
@@ -556,9 +600,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 pa = sload_px(job.src + (unsigned long long)base * 4 + ENC_SUB * 4, 4, 0u);
             }
         } else if (K != 2 && interior && (K == 1 || ch == 3)) {
+#ifdef SQOA_ENC_BUILTIN_DMA
             gcptr8 p = src + (size_t)base * 3;
             __builtin_amdgcn_global_load_lds(p + lane * 16, (lds_ptr)pre, 16, 0, 0);
             if (lane < 32) __builtin_amdgcn_global_load_lds(p + 1024 + lane * 16, (lds_ptr)(pre + 1024), 16, 0, 0);
+#else
+            lds_dma(job.src + (unsigned long long)base * 3, pre, true);
+#endif
             pb = sload_px(job.src + (unsigned long long)base * 3 - 3, 3, 0xff000000u);
             pa = sload_px(job.src + (unsigned long long)base * 3 + ENC_SUB * 3, 3, 0xff000000u);
             raw3 = true;
