@@ -33,6 +33,9 @@ constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
 constexpr int ENC_STG = 2624;          // staging bytes per wave: 5 B/px * 512, + 9 (run flush) + 12 (OR window) + 16 (clear), multiple of 16
 constexpr int ENC_PRE = ENC_SUB * 4;   // landing buffer of the next sub-tile's pixels (global -> LDS without passing VGPRs)
 constexpr uint32_t SPIN_MAX = 1u << 22;
+#ifndef SQOA_ENC_QTAB_SLEEP   // s_sleep argument between two polls of the colour-index hand-over tag (QOI-compat)
+#define SQOA_ENC_QTAB_SLEEP SQOA_ENC_SPIN_SLEEP
+#endif
 
 struct EncState {
     uint32_t bad;   // chain wait timed out (never expected)
@@ -288,6 +291,54 @@ SQOA_DEV SwarGroup sqoa_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, ui
     return sqoa_ops(R, G, B, A, DR, DG, DB, DA, XR, XB, XG, XA, H, L);
 }
 
+// The same for QOI-compat pixels that miss the colour index (seqoia.h:573-634): alpha moved -> RGBA; else DIFF if vr, vg, vb in
+// [-2, 1]; else LUMA; else RGB.  (Index hits are patched in afterwards: one byte, the slot.)
+SQOA_DEV SwarGroup qoi_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uint32_t Rp, uint32_t Gp, uint32_t Bp, uint32_t Ap,
+                             uint32_t H, uint32_t L) {
+    const uint32_t C08 = 0x08080808u, C20 = 0x20202020u, C02 = 0x02020202u, C40 = 0x40404040u, CFE = 0xfefefefeu, ONE = 0x01010101u;
+    const uint32_t MF0 = 0xf0f0f0f0u, MC0 = 0xc0c0c0c0u, M0F = 0x0f0f0f0fu, MFC = 0xfcfcfcfcu;
+    auto sub8 = [&](uint32_t a, uint32_t b) { return ((a | H) - (b & L)) ^ (~(a ^ b) & H); };
+    auto nz = [&](uint32_t x) { return (((x & L) + L) | x) & H; };  // 0x80 in every non-zero byte
+    auto full = [&](uint32_t z) { return (z - (z >> 7)) | z; };     // 0x80 -> 0xff
+    const uint32_t DR = sub8(R, Rp), DG = sub8(G, Gp), DB = sub8(B, Bp), DA = sub8(A, Ap);
+    const uint32_t DGm = ((DG | H) - C08) ^ ((DG & H) ^ H);                 // vg - 8
+    const uint32_t XR = sub8(DR, DGm), XB = sub8(DB, DGm);                  // vg_r + 8, vg_b + 8
+    const uint32_t XG = ((DG & L) + C20) ^ (DG & H);                        // vg + 32
+    const uint32_t ER = ((DR & L) + C02) ^ (DR & H), EG = ((DG & L) + C02) ^ (DG & H), EB = ((DB & L) + C02) ^ (DB & H);  // v + 2
+    const uint32_t z0 = nz(DR | DG | DB | DA);
+    const uint32_t ne_mask = full(z0), na_mask = full(nz(DA));
+    const uint32_t nd_mask = full(nz((ER | EG | EB) & MFC));                // DIFF does not fit
+    const uint32_t nl_mask = full(nz(((XR | XB) & MF0) | (XG & MC0)));      // LUMA does not fit
+    const uint32_t df_mask = ~na_mask & ~nd_mask, lu_mask = ~na_mask & nd_mask & ~nl_mask, rw_mask = na_mask | (nd_mask & nl_mask);
+    const uint32_t DIFFB = C40 | ((ER << 4) & 0x30303030u) | ((EG << 2) & 0x0c0c0c0cu) | (EB & 0x03030303u);   // seqoia.h:599
+    const uint32_t L0 = XG | H, L1 = ((XR << 4) & MF0) | (XB & M0F);
+    SwarGroup o;
+    o.W0 = ((DIFFB & df_mask) | (L0 & lu_mask) | (CFE & rw_mask) | (ONE & na_mask)) & ne_mask;  // 0xfe | 1 = 0xff
+    o.W1 = ((L1 & lu_mask) | (R & rw_mask)) & ne_mask;
+    o.W2 = G & rw_mask & ne_mask;
+    o.W3 = B & rw_mask & ne_mask;
+    o.AH = A & na_mask;
+    o.b0 = z0 >> 7;
+    o.Nn = (((ONE & df_mask) | ((ONE << 1) & lu_mask) | ((ONE << 2) & rw_mask)) + (ONE & na_mask)) & (ne_mask & (ONE * 7u));   // DIFF 1, LUMA 2, RGB 4, RGBA 5
+    return o;
+}
+
+// The index probe (seqoia.h:563-572) of one row of 64 consecutive pixels, lane = pixel, rows in order: a pixel's candidate is the
+// most recent earlier pixel of the row on its slot (per-slot lane masks in LDS), else the slot as the rows before left it.
+// Returns 0x80 | slot where the pixel hits, 0 where it misses or repeats its predecessor (`ne` false: run pixels do not probe).
+SQOA_DEV uint32_t qoi_probe_row(uint32_t px, bool ne, uint32_t* tabw, unsigned long long* smask, int lane, unsigned long long le_mask) {
+    const uint32_t h = qoi_hash(px);
+    uint32_t cand = tabw[h];
+    if (ne) __hip_atomic_fetch_or(&smask[h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const unsigned long long m = __hip_atomic_load(&smask[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const unsigned long long lower = m & (le_mask >> 1);
+    const int from = lower ? 63 - __builtin_clzll(lower) : lane;
+    const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
+    if (lower) cand = near;
+    if (ne && (m & ~le_mask) == 0ull) { tabw[h] = px; smask[h] = 0; }  // last writer of the slot in this row
+    return (ne && cand == px) ? 0x80u | h : 0u;
+}
+
 // Phase A: per-channel byte planes of four rows, op decision for every pixel, and the rows' equality masks.
 template <bool QOI>
 SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup (&grp)[ENC_S / 4], unsigned long long (&E)[ENC_S]) {
@@ -490,7 +541,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                                                         sqoa_hip_result* __restrict__ results,
                                                         const uint32_t* __restrict__ qtab_in) {   // QOI strip jobs: the colour index entering job i at [64 * i, 64 * i + 64); else null
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
-    __shared__ __attribute__((aligned(16))) uint8_t s_pre[W][ENC_PRE];
+    // (QOI-compat, L8 hot loop: two landing buffers per wave, taken in turn -- the sub-tile being encoded stays readable in LDS for
+    // the row-by-row index probe while the next one lands -- and 512 bytes for the probe's verdicts, one byte per pixel)
+    __shared__ __attribute__((aligned(16))) uint8_t s_pre[QOI ? 2 * W : W][ENC_PRE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hit[QOI ? W : 1][QOI ? ENC_SUB : 16];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
     // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
@@ -498,13 +552,14 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     constexpr int QW = QOI ? W : 1;
     __shared__ uint32_t s_tabw[QW][64];
     __shared__ uint32_t s_stamp[QW][64];
+    __shared__ unsigned long long s_last[QOI ? W : 1][QOI ? 64 : 1];   // L8 hot loop: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer
     __shared__ unsigned long long s_smask[QW][64];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
     __shared__ uint32_t s_tabtag[2][W];
     // L8 path: run bytes of the 8 consecutive pixels a lane owns, by their 8 "repeats its predecessor" flags: byte j =
     // 0xc0 | (c - 1) where c = repeated pixels ending at pixel j inside the lane (the byte a run flushes as when it ends
     // there and began inside the lane, seqoia.h:554-561), 0 where pixel j does not repeat
-    __shared__ __attribute__((aligned(8))) uint32_t s_runtab[QOI ? 1 : 256][2];
+    __shared__ __attribute__((aligned(8))) uint32_t s_runtab[256][2];
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
@@ -529,9 +584,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
     uint8_t* stage = s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
-    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; }
+    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; s_last[w % QW][lane] = 0; }
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
-    if constexpr (!QOI) {
+    {
         for (uint32_t e8 = threadIdx.x; e8 < 256u; e8 += W * 64) {
             unsigned long long v = 0;
             uint32_t c = 0;
@@ -571,7 +626,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
     bool cur_raw3 = false;
-    uint8_t* pre = s_pre[w];
+    uint8_t* pre = s_pre[w];                       // where the next sub-tile lands
+    uint8_t* held = s_pre[QOI ? W + w : w];        // QOI-compat: the buffer the current sub-tile's pixels were taken from
     // The pixels of a wave's NEXT sub-tile travel global -> LDS directly (global_load_lds_dwordx4, any source alignment:
     // tools/ubench/lds_dma_align.hip), two instructions per 512 pixels, and are picked up into VGPRs only when the current
     // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
@@ -623,6 +679,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             for (int s = 0; s < ENC_S; ++s) reinterpret_cast<uint32_t*>(pre)[s * 64 + lane] = px[s];
         }
     };
+    // (QOI-compat: the buffer just taken from becomes `held` -- it keeps the sub-tile readable -- and the other one the landing buffer)
+    auto swap_buffers = [&]() { if constexpr (QOI) { uint8_t* t = held; held = pre; pre = t; } };
     auto take = [&](uint32_t (&px)[ENC_S], bool raw3) {
         // the compiler does not order LDS reads behind LDS-DMA loads by itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -637,6 +695,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) px[s] = reinterpret_cast<const uint32_t*>(pre)[s * 64 + lane];
         }
+        swap_buffers();
     };
 
     // L8 layout (below): the lane's eight consecutive pixels instead of one pixel of each row
@@ -650,6 +709,31 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         } else {
             const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
             px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+        }
+        swap_buffers();
+    };
+
+    // QOI-compat, L8 hot loop (j > 0, sub-tiles follow): the colour index entering sub-tile j and the one leaving it.  `writers`
+    // marks the sub-tile's last writer per slot (stamps) and puts their pixels into the table to be published; the slots the
+    // sub-tile does not write are filled from the table the sub-tile in front published (composition by overwrite).
+    auto qoi_table_hop = [&](uint32_t j, bool, auto&& writers) {
+        if constexpr (QOI) {
+            unsigned long long* last = s_last[w % QW];
+            uint32_t* pub = s_tabpub[(j / W) & 1][w % QW];
+            writers(last);
+            const uint32_t pp = ((j - 1) / W) & 1, pw = (j - 1) % W;
+            for (uint32_t spin = 0;; ++spin) {
+                const uint32_t t = __hip_atomic_load(&s_tabtag[pp][pw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bcast_first(t) == j) break;
+                if (spin >= SPIN_MAX) { st.bad = 1; break; }
+                if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_QTAB_SLEEP);
+            }
+            const uint32_t tin = s_tabpub[pp][pw % QW][lane];
+            const unsigned long long e = last[lane];
+            pub[lane] = (uint32_t)(e >> 32) ? (uint32_t)e : tin;
+            s_tabw[w % QW][lane] = tin;
+            last[lane] = 0;
+            if (lane == 0) __hip_atomic_store(&s_tabtag[(j / W) & 1][w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
 
@@ -754,7 +838,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     const uint32_t t = __hip_atomic_load(&s_tabtag[pp][pw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (bcast_first(t) == j) break;
                     if (spin >= SPIN_MAX) { st.bad = 1; break; }
-                    if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
+                    if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_QTAB_SLEEP);
                 }
                 tin = s_tabpub[pp][pw % QW][lane];
             }
@@ -908,7 +992,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // scan per sub-tile.  Runs that cross lanes (flat areas) take a per-lane fix-up behind a wave-uniform branch.
     auto body8 = [&](auto px3_tag, uint32_t j, bool next8) {
         constexpr bool PX3 = decltype(px3_tag)::value;  // 3-byte pixels: cur[0..5] hold the lane's 24 bytes
-        if constexpr (!QOI) {
+        {
         typedef __attribute__((address_space(3))) uint32_t* lds_u32;
         __builtin_assume(j > 0);
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
@@ -943,7 +1027,21 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         unsigned long long* my_run = &s_run[(j / W) & 1][w];
         unsigned long long* prev_run = &s_run[((j - 1) / W) & 1][(j - 1) % W];
         uint32_t sbase = 0;
-        if (flat) {
+        if (flat && QOI) {
+            // QOI-compat runs are cut every 62 pixels (seqoia.h:411, :546-549): k runs over c_in+1 .. c_in+512, a 0xfd at every
+            // multiple of 62 -- floor((c_in + 512) / 62) - floor(c_in / 62) of them, 8 or 9 --, and behind the last pixel the flush
+            // of the remainder (seqoia.h:554-561) if the run ends here.  Run pixels never touch the colour index (seqoia.h:544-550
+            // come before :563): the table entering the sub-tile is the one leaving it.
+            const uint32_t c_in = chain_wait(prev_run, j, st);
+            chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
+            const uint32_t kend = c_in + ENC_SUB, qend = kend / 62u;
+            const uint32_t nfd = qend - c_in / 62u, r = kend - 62u * qend;
+            uint32_t nbytes = nfd, last = 0;
+            if (r != 0u && pa != pb) { last = 0xc0u | (r - 1u); nbytes = nfd + 1u; }
+            if ((uint32_t)lane < nbytes) stage[lane] = (uint32_t)lane < nfd ? (uint8_t)0xfd : (uint8_t)last;   // (the buffer is zeroed, position-independent)
+            sbase = nbytes;
+            qoi_table_hop(j, false, [](unsigned long long*) {});
+        } else if (flat) {
             const uint32_t c_in = chain_wait(prev_run, j, st);
             chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
             // k runs over c_in+1 .. c_in+512: exactly one of them is a multiple of 512 (0xfd, seqoia.h:546-549); the
@@ -990,10 +1088,14 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             // predecessor planes: a byte shift inside the lane; the first pixel takes the lane below's last one (lane 0: pb)
             const uint32_t qR = shift_up1(R1, pb << 24), qG = shift_up1(G1, (pb << 16) & 0xff000000u),
                            qB = shift_up1(B1, (pb << 8) & 0xff000000u), qA = shift_up1(A1, pb & 0xff000000u);
-            const SwarGroup g0 = sqoa_group(R0, G0, B0, A0, __builtin_amdgcn_alignbyte(R0, qR, 3), __builtin_amdgcn_alignbyte(G0, qG, 3),
-                                            __builtin_amdgcn_alignbyte(B0, qB, 3), __builtin_amdgcn_alignbyte(A0, qA, 3), Hv, L7);
-            const SwarGroup g1 = sqoa_group(R1, G1, B1, A1, __builtin_amdgcn_alignbyte(R1, R0, 3), __builtin_amdgcn_alignbyte(G1, G0, 3),
-                                            __builtin_amdgcn_alignbyte(B1, B0, 3), __builtin_amdgcn_alignbyte(A1, A0, 3), Hv, L7);
+            auto group = [&](uint32_t R, uint32_t G, uint32_t B, uint32_t A, uint32_t Rp, uint32_t Gp, uint32_t Bp, uint32_t Ap) {
+                if constexpr (QOI) return qoi_group(R, G, B, A, Rp, Gp, Bp, Ap, Hv, L7);
+                else return sqoa_group(R, G, B, A, Rp, Gp, Bp, Ap, Hv, L7);
+            };
+            SwarGroup g0 = group(R0, G0, B0, A0, __builtin_amdgcn_alignbyte(R0, qR, 3), __builtin_amdgcn_alignbyte(G0, qG, 3),
+                                 __builtin_amdgcn_alignbyte(B0, qB, 3), __builtin_amdgcn_alignbyte(A0, qA, 3));
+            SwarGroup g1 = group(R1, G1, B1, A1, __builtin_amdgcn_alignbyte(R1, R0, 3), __builtin_amdgcn_alignbyte(G1, G0, 3),
+                                 __builtin_amdgcn_alignbyte(B1, B0, 3), __builtin_amdgcn_alignbyte(A1, A0, 3));
             // ---- runs (seqoia.h:544-561): e = 1 where a pixel repeats its predecessor, l = 1 where a run ends
             const uint32_t e0 = g0.b0 ^ ONE, e1 = g1.b0 ^ ONE;
             const uint32_t e0n = shift_down1(e0, pa == last_px ? 1u : 0u);  // the lane above's first four flags; lane 63: the pixel after the sub-tile
@@ -1008,6 +1110,54 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             const uint32_t tzl = (uint32_t)__builtin_clzll(~allq);
             const uint32_t Ea = (uint32_t)__builtin_amdgcn_readlane((int)E8, (int)(63u - tzl));
             chain_post(my_run, j + 1, 8u * tzl + (uint32_t)__builtin_clz((~Ea << 24) | 0x00800000u), lane);
+            if constexpr (QOI) {
+                // ---- the colour index (seqoia.h:563-582) stays in PIXEL order across lanes: the sub-tile's pixels are read once more,
+                // row by row (lane = pixel of a row of 64) from the landing buffer they were taken from, probed row after row exactly as
+                // in the row layout, and each pixel's verdict (0x80 | slot: hit) goes back through 512 bytes of LDS, where the lane
+                // that owns the pixel finds the verdicts of its eight as two dwords -- byte planes like all the others
+                const unsigned long long le_mask = (2ull << (uint32_t)lane) - 1ull;
+                uint32_t rowpx[ENC_S], nebits = 0;
+                {
+                    uint32_t carry = pb;
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        uint32_t v;
+                        if constexpr (PX3) { __builtin_memcpy(&v, held + 3 * (r * 64 + lane), 4); v |= 0xff000000u; }
+                        else v = reinterpret_cast<const uint32_t*>(held)[r * 64 + lane];
+                        rowpx[r] = v;
+                        nebits |= (v != shift_up1(v, carry) ? 1u : 0u) << r;
+                        carry = bcast_lane(v, 63);
+                    }
+                }
+                uint8_t* hit = s_hit[w];
+                qoi_table_hop(j, true, [&](unsigned long long* last) {
+#ifdef SQOA_DBG_Q_NOSTAMP
+                    return;
+#endif
+                    // last non-run pixel per slot inside the sub-tile: the table only ever holds the most recent writer of each slot
+                    // (hit or miss, seqoia.h:566-571), so it composes by overwrite.  One ds_max_u64 of position | pixel per row.
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r)
+                        if ((nebits >> r) & 1u) atomicMax(&last[qoi_hash(rowpx[r])], (unsigned long long)(r * 64 + lane + 1) << 32 | rowpx[r]);
+                });
+#pragma unroll
+                for (int r = 0; r < ENC_S; ++r)
+#ifdef SQOA_DBG_Q_NOPROBE   // timing experiments only (wrong output)
+                    hit[r * 64 + lane] = 0;
+#else
+                    hit[r * 64 + lane] = (uint8_t)qoi_probe_row(rowpx[r], (nebits >> r) & 1u, s_tabw[w], s_smask[w], lane, le_mask);
+#endif
+                const uint2 hv = *reinterpret_cast<const uint2*>(hit + 8 * lane);
+                // QOI_OP_INDEX where the pixel hits: one byte, the slot (seqoia.h:566-568)
+                auto index_op = [&](uint32_t h4, SwarGroup& G, uint32_t& W0, uint32_t& Nn) {
+                    const uint32_t z = h4 & Hv, m = (z - (z >> 7)) | z;
+                    W0 = (W0 & ~m) | (h4 & 0x3f3f3f3fu & m);
+                    G.W1 &= ~m; G.W2 &= ~m; G.W3 &= ~m; G.AH &= ~m;
+                    Nn = (Nn & ~m) | (ONE & m);
+                };
+                index_op(hv.x, g0, W00, Nn0);
+                index_op(hv.y, g1, W01, Nn1);
+            }
             uint32_t big = 0, big_at = 0;  // run remainder >= 62 (seqoia.h:555-559): q << 8 | last byte, and the pixel that owns it
 #ifdef SQOA_DBG_NOCARRY
             if (false) {
@@ -1032,8 +1182,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t carry = below_ne >= 0 ? (uint32_t)(8 * lane - 1 - below_ne) : 8u * (uint32_t)lane + c_in;
                 // my leading run ends in my stretch iff a pixel of mine follows it, or (all eight repeat) the pixel after my last does not
                 const bool ends = (f - 1u < 7u) || (f == 8u && (l1 >> 24) != 0u);
-                const uint32_t r = (carry + f) & 511u;
-                const uint32_t q = ((r - 1u) * 1075u) >> 16;                                     // (r - 1) / 61 for 1 <= r <= 511
+                // the run's remainder where it ends: k mod 512 (mod 62: QOI-compat, seqoia.h:411-412; there it is at most 61: one byte)
+                const uint32_t kk = carry + f;
+                const uint32_t r = QOI ? kk - 62u * (uint32_t)(((unsigned long long)kk * 0x84210843ull) >> 37) : kk & 511u;
+                const uint32_t q = QOI ? 0u : ((r - 1u) * 1075u) >> 16;                          // (r - 1) / 61 for 1 <= r <= 511
                 const uint32_t lastb = 0xc0u | (r - 1u - 61u * q);
                 // one byte of the (W0, Nn) planes of my eight pixels replaced (per 32-bit half: the same through 64-bit values
                 // measured 12 % slower on the whole kernel)
@@ -1049,8 +1201,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t pe = (f - 1u) & 7u;
                 patch(pe, r == 0u ? 0xfdu : q == 0u ? lastb : 0u, r == 0u ? 1u : q + 1u, ends);
                 if (ends && r != 0u && q != 0u) { big = q << 8 | lastb; big_at = pe; }
-                // every 512th pixel of the run (rare)
-                const uint32_t jfd = 511u - (carry & 511u);
+                // every 512th (62nd) pixel of the run
+                const uint32_t cm = QOI ? carry - 62u * (uint32_t)(((unsigned long long)carry * 0x84210843ull) >> 37) : carry & 511u;
+                const uint32_t jfd = (QOI ? 61u : 511u) - cm;
                 const bool hasfd = jfd < f;
                 if (__ballot(hasfd) != 0ull) patch(jfd & 7u, 0xfdu, 1u, hasfd);
             }
@@ -1136,7 +1289,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         // wave's to prefetch (j + W < nfull - 1 ... all three known at compile time); the few others take the general instance
         const uint32_t nmid = nfull > (uint32_t)W + 1u ? nfull - (uint32_t)W - 1u : 0u;  // j + W is interior as well
 #if !defined(SQOA_ENC_L8) || SQOA_ENC_L8
-        const bool l8 = !QOI && (ch == 3 || (ch == 4 && (job.src & 3ull) == 0));  // the hot loop of SQOA colour images runs the L8 body (4-byte pixels: dword-aligned)
+#ifndef SQOA_ENC_QOI_L8
+#define SQOA_ENC_QOI_L8 1
+#endif
+        const bool l8 = (!QOI || SQOA_ENC_QOI_L8) && (ch == 3 || (ch == 4 && (job.src & 3ull) == 0));  // the hot loop of colour images runs the L8 body (4-byte pixels: dword-aligned)
 #else
         const bool l8 = false;
 #endif
@@ -1152,8 +1308,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 body(std::true_type{}, kind_tag, j, true);
             }
         };
-        if constexpr (!QOI) {
-            // SQOA: the hot loop is the L8 body; 4-byte pixels at an address that is not dword-aligned (rare) stay on the general one
+        {
+            // the hot loop is the L8 body (round 3: QOI-compat too); 4-byte pixels at an address that is not dword-aligned (rare) stay on the general one
             auto loop8 = [&](auto px3_tag) {
                 for (; j < nmid; j += W) {
                     if (j >= thr) {
@@ -1167,9 +1323,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             };
             if (l8 && ch == 4) loop8(std::false_type{});
             else if (l8) loop8(std::true_type{});
-        } else {
-            if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
-            else hot_loop(std::integral_constant<int, 1>{});
+            else if constexpr (QOI) {
+                if (ch == 4) hot_loop(std::integral_constant<int, 2>{});
+                else hot_loop(std::integral_constant<int, 1>{});
+            }
         }
         for (; j < nfull; j += W) body(std::true_type{}, std::integral_constant<int, 0>{}, j, j + W < nfull);  // the image's last full sub-tile
 #else
