@@ -705,7 +705,19 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         if (raw3) {
             const uint2 a = *reinterpret_cast<const uint2*>(pre + 24 * lane), b = *reinterpret_cast<const uint2*>(pre + 24 * lane + 8),
                         c = *reinterpret_cast<const uint2*>(pre + 24 * lane + 16);
-            px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y; px[6] = 0; px[7] = 0;
+            if constexpr (QOI) {
+                // QOI-compat: the index probe reads the sub-tile once more, row by row (body8) -- 3-byte pixels would be 8 unaligned LDS
+                // reads per lane there, which stall the LDS pipe (4096 x 512 x 512 RGB icons 4.35 ms against 3.01 ms as RGBA).  The lane's
+                // 24 bytes become eight pixel dwords (alpha 255) here, go back into the same buffer (every lane has read before any
+                // lane writes: in place), and from here on the sub-tile is a 4-byte one.
+                auto rgb = [](uint32_t x) { return (x & 0x00ffffffu) | 0xff000000u; };
+                px[0] = rgb(a.x); px[1] = rgb(__builtin_amdgcn_alignbyte(a.y, a.x, 3)); px[2] = rgb(__builtin_amdgcn_alignbyte(b.x, a.y, 2)); px[3] = rgb(b.x >> 8);
+                px[4] = rgb(b.y); px[5] = rgb(__builtin_amdgcn_alignbyte(c.x, b.y, 3)); px[6] = rgb(__builtin_amdgcn_alignbyte(c.y, c.x, 2)); px[7] = rgb(c.y >> 8);
+                *reinterpret_cast<u32x4*>(pre + 32 * lane) = u32x4{px[0], px[1], px[2], px[3]};
+                *reinterpret_cast<u32x4*>(pre + 32 * lane + 16) = u32x4{px[4], px[5], px[6], px[7]};
+            } else {
+                px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y; px[6] = 0; px[7] = 0;
+            }
         } else {
             const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
             px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
@@ -991,14 +1003,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // look-up on the lane's 8 repeat flags, and the byte offsets are one in-register prefix per four pixels plus ONE wave
     // scan per sub-tile.  Runs that cross lanes (flat areas) take a per-lane fix-up behind a wave-uniform branch.
     auto body8 = [&](auto px3_tag, uint32_t j, bool next8) {
-        constexpr bool PX3 = decltype(px3_tag)::value;  // 3-byte pixels: cur[0..5] hold the lane's 24 bytes
+        constexpr bool SRC3 = decltype(px3_tag)::value; // 3-byte pixels in memory
+        constexpr bool PX3 = SRC3 && !QOI;              // ... and in cur[0..5]: the lane's 24 bytes as they lie (QOI-compat: take8 has made dwords of them)
         {
         typedef __attribute__((address_space(3))) uint32_t* lds_u32;
         __builtin_assume(j > 0);
         NbrPx nxt_pb{0u, 0u, 0u, 0u}, nxt_pa{0u, 0u, 0u, 0u};
         bool nxt_raw3 = false;
         PHASE(7);
-        fetch(std::integral_constant<int, PX3 ? 1 : 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
+        fetch(std::integral_constant<int, SRC3 ? 1 : 2>{}, j + W, nxt_pb, nxt_pa, nxt_raw3);
         PHASE(0);
         const uint32_t pb = cur_pb, pa = cur_pa;
         // channel planes of my two groups of four pixels (byte i = pixel 4g + i)
@@ -1144,6 +1157,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 for (int r = 0; r < ENC_S; ++r)
 #ifdef SQOA_DBG_Q_NOPROBE   // timing experiments only (wrong output)
                     hit[r * 64 + lane] = 0;
+#elif defined(SQOA_ENC_Q_ROWSKIP)
+                {
+                    uint32_t hb = 0;
+                    if (__ballot((nebits >> r) & 1u) != 0ull) hb = qoi_probe_row(rowpx[r], (nebits >> r) & 1u, s_tabw[w], s_smask[w], lane, le_mask);
+                    hit[r * 64 + lane] = (uint8_t)hb;
+                }
 #else
                     hit[r * 64 + lane] = (uint8_t)qoi_probe_row(rowpx[r], (nebits >> r) & 1u, s_tabw[w], s_smask[w], lane, le_mask);
 #endif
@@ -1258,7 +1277,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         }
         PHASE(3);
         // this sub-tile's pixels are dead: pick up the next one's
-        if (next8) take8(cur, PX3); else take(cur, PX3);
+        if (next8) take8(cur, SRC3); else take(cur, SRC3);
         cur_pb = nxt_pb.value();
         cur_pa = nxt_pa.value();
         PHASE(4);
