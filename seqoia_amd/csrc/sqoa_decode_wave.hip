@@ -387,7 +387,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         if (more) load_chunk(c + W, stg);
         const uint32_t gs = p0 + c * DEC_CHUNK;               // stream offset of chunk byte 0
         const uint8_t* cb = reinterpret_cast<const uint8_t*>(lds) + (gs & 3u);
-        const uint8_t* lb = cb + DEC_LB * lane;                // this lane's 8 bytes
+        [[maybe_unused]] const uint8_t* lb = cb + DEC_LB * lane;                // this lane's 8 bytes
         const bool last_chunk = IN ? false : c == nchunks - 1;
         // how many of my bytes lie inside the chunk area (op starts beyond it do not exist, seqoia.h:726)
         const uint32_t my0 = gs + DEC_LB * lane;
@@ -395,7 +395,18 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
         // ---- 1. parse: each lane composes the transition functions of its 8 bytes, one wave scan ----
         uint32_t qd[DEC_LB / 4];
-        __builtin_memcpy(qd, lb, DEC_LB);
+#ifdef SQOA_DEC_UNALIGNED_PARSE_READ
+        __builtin_memcpy(qd, lb, DEC_LB);   // one ds_read_b64 at a byte address that is 3 mod 4 (the chunk area starts behind 15 header bytes): stalls the LDS pipe
+#else
+        {   // three aligned dwords and two v_alignbyte_b32 (as the walk's windows)
+            static_assert(DEC_LB == 8, "parse read");
+            const uint32_t off = (gs & 3u) + DEC_LB * lane;
+            const uint32_t* pw = lds + (off >> 2);
+            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            qd[0] = __builtin_amdgcn_alignbyte(d1, d0, off & 3u);
+            qd[1] = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
+        }
+#endif
         Fn F{ID_LO, ID_HI};
 #pragma unroll
         for (int k = 0; k < DEC_LB; ++k) {
