@@ -46,8 +46,9 @@ typedef struct {
 /* Strip jobs: one image encoded by several jobs (several workgroups), each given a stretch of consecutive pixels
  * (desc.width * desc.height = the stretch's pixel count, src = its first pixel).  A stretch must START at a pixel that
  * differs from its predecessor (no run crosses a cut); then the jobs' streams, concatenated in pixel order behind the
- * 15-byte header the caller writes (reference seqoia.h:497-514), are byte-identical to the one-job stream.  The legacy
- * sqoa_encode uses this for large images; batch callers encode whole images per job and leave `reserved` 0. */
+ * 15-byte header the caller writes (reference seqoia.h:497-514), are byte-identical to the one-job stream.  For callers
+ * that cut images themselves, SQOA-native only; callers that hand over whole images leave `reserved` 0 -- a plan cuts few large
+ * images into strips on the device by itself, QOI-compat ones too (it hands the colour index from strip to strip). */
 #define SQOA_HIP_JOB_NOHEADER 1u /* no header in front of the ops */
 #define SQOA_HIP_JOB_NOEND    2u /* more pixels follow in another job: no end marker, a trailing run is flushed as a run that ends */
 #define SQOA_HIP_JOB_PREV     4u /* the first pixel's predecessor is the pixel in front of src (readable), not (0,0,0,255) */

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 const Fn Fi = wave_compose_scan(Fn{live ? s_wg[0][lane] : ID_LO, live ? s_wg[1][lane] : ID_HI});
                 if (lane == 63) { row->g_lo = Fi.lo; row->g_hi = Fi.hi; }
             } else {
-                uint32_t v = live ? s_wg[0][lane] : 0u;   // (<= N each; 16 of them: no 32-bit overflow, N < 400 000 000)
+                uint32_t v = live ? s_wg[0][lane] : 0u;   // (a 512-byte chunk yields at most 512 x 512 = 2^18 pixels -- its counts are not clamped to N before this -- and a workgroup has at most 64 chunks: 2^24, no 32-bit overflow)
                 v = wave_incl_scan(v);
                 const Xf Ti = wave_xf_scan(Xf{live ? s_wg[1][lane] : 0u, live ? s_wg[2][lane] : 0u});
                 if (lane == 63) { row->ctot = v > N ? N : v; row->tv = Ti.v; row->tabs = Ti.abs; }
