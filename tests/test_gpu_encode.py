@@ -389,15 +389,16 @@ def test_repeated_launches_are_bit_identical(sq, orc, mode):
     dec.close(); enc.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("ch", [3, 4])
-def test_l8_hot_loop_runs_of_every_length(sq, orc, ch):
+def test_l8_hot_loop_runs_of_every_length(sq, orc, ch, mode):
     """The hot loop of colour images gives every lane eight consecutive pixels; runs then start, end and cross the 512th
     repeat at every position inside a lane, across lanes and across sub-tiles (seqoia.h:544-561).  Images large enough
     that nearly all sub-tiles take that loop, filled with runs of random lengths (1 .. 1400, dense around the 61 / 62 /
     511 / 512 boundaries) separated by one to three literal pixels of every op kind."""
     import torch
 
-    rng = np.random.default_rng(1234 + ch)
+    rng = np.random.default_rng(1234 + ch + 10 * mode)   # (qoi_compat=1: runs are cut every 62 pixels, seqoia.h:411)
     o = orc.best()
     w, h, n = 512, 160, 6
     imgs = []
@@ -433,11 +434,48 @@ def test_l8_hot_loop_runs_of_every_length(sq, orc, ch):
                 p += 1
         imgs.append(px.reshape(-1))
     t = torch.from_numpy(np.stack(imgs).reshape(n, h, w, ch)).cuda()
-    plan = sq.EncodePlan(t, qoi_compat=0)
+    plan = sq.EncodePlan(t, qoi_compat=mode)
     plan.launch()
     assert (plan.results()["status"] == 0).all()
     for k, s in enumerate(plan.streams()):
-        want = o.encode(imgs[k], w, h, ch, 0)
+        want = o.encode(imgs[k], w, h, ch, mode)
+        assert s == want, (ch, k, len(s), len(want), next((i for i in range(min(len(s), len(want))) if s[i] != want[i]), None))
+    plan.close()
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+def test_qoi_l8_hot_loop_index_hits_everywhere(sq, orc, ch):
+    """QOI-compat, the L8 hot loop: few colours that recur at every distance -- inside a lane's eight pixels, across lanes, across
+    the 64-pixel rows the probe walks, across sub-tiles and waves -- so that most ops are QOI_OP_INDEX hits and the slots are
+    overwritten by colliding colours now and then (seqoia.h:563-582); with (0,0,0,0), whose slot 0 the zeroed table holds from
+    the start, and with short runs and small deltas (DIFF / LUMA) mixed in."""
+    import torch
+
+    o = orc.best()
+    w, h, n = 512, 96, 8
+    imgs = []
+    for k in range(n):
+        rng = np.random.default_rng(4321 + 17 * k + ch)
+        ncol = [2, 3, 5, 9, 17, 40, 70, 200][k]
+        pal = rng.integers(0, 256, size=(ncol, ch), dtype=np.uint8)
+        if k % 2 == 0:
+            pal[0] = 0                                              # (0,0,0[,0])
+        idx = rng.integers(0, ncol, size=w * h)
+        px = pal[idx].astype(np.int32)
+        wob = rng.integers(0, 8, size=w * h)                        # small deltas on some pixels: DIFF / LUMA between the hits
+        px[:, 0] = (px[:, 0] + (wob == 1) - (wob == 2)) % 256
+        px[:, 1] = (px[:, 1] + 3 * (wob == 3)) % 256
+        rep = rng.integers(0, 10, size=w * h) == 0                  # short runs
+        for i in np.nonzero(rep)[0]:
+            px[i:i + int(rng.integers(1, 9))] = px[i]
+        imgs.append(px.astype(np.uint8).reshape(-1))
+    t = torch.from_numpy(np.stack(imgs).reshape(n, h, w, ch)).cuda()
+    plan = sq.EncodePlan(t, qoi_compat=1)
+    for _ in range(2):
+        plan.launch()
+    assert (plan.results()["status"] == 0).all()
+    for k, s in enumerate(plan.streams()):
+        want = o.encode(imgs[k], w, h, ch, 1)
         assert s == want, (ch, k, len(s), len(want), next((i for i in range(min(len(s), len(want))) if s[i] != want[i]), None))
     plan.close()
 
