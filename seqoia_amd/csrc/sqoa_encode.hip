@@ -543,8 +543,11 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[W][ENC_STG];
     // (QOI-compat, L8 hot loop: two landing buffers per wave, taken in turn -- the sub-tile being encoded stays readable in LDS for
     // the row-by-row index probe while the next one lands -- and 512 bytes for the probe's verdicts, one byte per pixel)
-    __shared__ __attribute__((aligned(16))) uint8_t s_pre[QOI ? 2 * W : W][ENC_PRE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_hit[QOI ? W : 1][QOI ? ENC_SUB : 16];
+    // (the one-wave shape for many small images, W = 1, keeps the row layout for QOI-compat: its images are a handful of sub-tiles,
+    // and 4.6 KB more LDS per workgroup cost it more workgroups per CU than the layout gains: 4096 x 64 x 64 icons 0.092 -> 0.100 ms)
+    constexpr bool QL8 = QOI && W > 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_pre[QL8 ? 2 * W : W][ENC_PRE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hit[QL8 ? W : 1][QL8 ? ENC_SUB : 16];
     __shared__ unsigned long long s_run[2][W];
     __shared__ unsigned long long s_pos[W];
     // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     constexpr int QW = QOI ? W : 1;
     __shared__ uint32_t s_tabw[QW][64];
     __shared__ uint32_t s_stamp[QW][64];
-    __shared__ unsigned long long s_last[QOI ? W : 1][QOI ? 64 : 1];   // L8 hot loop: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer
+    __shared__ unsigned long long s_last[QL8 ? W : 1][QL8 ? 64 : 1];   // L8 hot loop: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer
     __shared__ unsigned long long s_smask[QW][64];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
     __shared__ uint32_t s_tabtag[2][W];
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
     uint8_t* stage = s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
-    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; s_last[w % QW][lane] = 0; }
+    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QW][lane] = 0; }
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
     {
         for (uint32_t e8 = threadIdx.x; e8 < 256u; e8 += W * 64) {
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
     bool cur_raw3 = false;
     uint8_t* pre = s_pre[w];                       // where the next sub-tile lands
-    uint8_t* held = s_pre[QOI ? W + w : w];        // QOI-compat: the buffer the current sub-tile's pixels were taken from
+    uint8_t* held = s_pre[QL8 ? W + w : w];        // QOI-compat: the buffer the current sub-tile's pixels were taken from
     // The pixels of a wave's NEXT sub-tile travel global -> LDS directly (global_load_lds_dwordx4, any source alignment:
     // tools/ubench/lds_dma_align.hip), two instructions per 512 pixels, and are picked up into VGPRs only when the current
     // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         }
     };
     // (QOI-compat: the buffer just taken from becomes `held` -- it keeps the sub-tile readable -- and the other one the landing buffer)
-    auto swap_buffers = [&]() { if constexpr (QOI) { uint8_t* t = held; held = pre; pre = t; } };
+    auto swap_buffers = [&]() { if constexpr (QL8) { uint8_t* t = held; held = pre; pre = t; } };
     auto take = [&](uint32_t (&px)[ENC_S], bool raw3) {
         // the compiler does not order LDS reads behind LDS-DMA loads by itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1311,7 +1314,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #ifndef SQOA_ENC_QOI_L8
 #define SQOA_ENC_QOI_L8 1
 #endif
-        const bool l8 = (!QOI || SQOA_ENC_QOI_L8) && (ch == 3 || (ch == 4 && (job.src & 3ull) == 0));  // the hot loop of colour images runs the L8 body (4-byte pixels: dword-aligned)
+        const bool l8 = (!QOI || (QL8 && SQOA_ENC_QOI_L8)) && (ch == 3 || (ch == 4 && (job.src & 3ull) == 0));  // the hot loop of colour images runs the L8 body (4-byte pixels: dword-aligned)
 #else
         const bool l8 = false;
 #endif
