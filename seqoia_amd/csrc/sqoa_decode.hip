@@ -525,6 +525,9 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
                                               sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
+extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
+                                                  const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
+                                                  hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                 const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, hipStream_t stream);
 
@@ -537,6 +540,10 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     const int n_multi = dp ? dp->n_images : 0;
     hipError_t e = hipSuccess;
     if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, stream);
+    if (e != hipSuccess) return e;
+    // the QOI-compat streams among them: speculative chip-wide pass + check (sqoa_decode_qoi.hip); what fails the check stays SLOWPATH
+    if (n_multi && !wave_only) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,
+                                                               dp->d_qstate, dp->per, stream);
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, small, d_results, stream);
     if (e != hipSuccess) return e;

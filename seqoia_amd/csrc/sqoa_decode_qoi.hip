@@ -94,10 +94,29 @@ SQOA_DEV uint32_t select_mask(uint32_t if_clear, uint32_t if_set, unsigned long 
     return r;
 }
 
-template <int W>
+// What the speculative pass (SPEC, below) leaves per workgroup for the check that follows it: the resolver's state -- running pixel and
+// the 64 index entries -- where the workgroup's own chunks begin (behind its warm-up) and where they end.
+struct dq_state { uint32_t px, tab[64], pad[63]; };   // 512 bytes
+struct dp_chunk_row { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };   // = sqoa::dp_chunk (sqoa_decode_wave.hip)
+
+// SPEC = false: one workgroup per stream, from its first byte (the batch shape).
+// SPEC = true: the chip-wide route for FEW LARGE QOI-compat streams.  A stream's decoder state (pixel, index[64]) cannot be summarised
+// over a range of ops, but it can be GUESSED: a workgroup takes a range of `per` chunks and first decodes the `per`
+// chunks in front of it from a reset state (pixel (0,0,0,255), index all zero) without storing anything -- on photo-like content
+// every index slot has been rewritten and the pixel re-anchored by an RGB op long before its own chunks begin.  Parser states and
+// pixel positions are exact (passes 1 and 2 of decode_wave_kernel + the two scans).  Every workgroup leaves its state at the start
+// and at the end of its own chunks; dq_verify_kernel accepts the stream only if EVERY workgroup's guessed start state equals the
+// end state of the workgroup in front -- by induction from the first one, which starts exactly, all pixels are then the
+// reference's -- and leaves it to the one-workgroup decoder (status still SLOWPATH) otherwise.
+template <int W, bool SPEC = false>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_qoi_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                                                    const int* __restrict__ job_ids,
-                                                                                                   sqoa_hip_result* __restrict__ results) {
+                                                                                                   sqoa_hip_result* __restrict__ results,
+                                                                                                   const dp_image* __restrict__ dp_images = nullptr,
+                                                                                                   const dp_wg* __restrict__ dp_wgs = nullptr,
+                                                                                                   const dp_chunk_row* __restrict__ dp_tab = nullptr,
+                                                                                                   const uint32_t* __restrict__ dp_flags = nullptr,
+                                                                                                   dq_state* __restrict__ dq = nullptr, uint32_t dp_per = 0) {
     constexpr int P = W - 1;                       // producer waves; wave 0 is the resolver
     __shared__ uint32_t s_bytes[P][QK_LDS_DW];
     __shared__ uint32_t s_ftab[256];               // byte -> low half of its parser transition function
@@ -119,7 +138,15 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
-    const int jid = job_ids[blockIdx.x];
+    uint32_t chunk_first = 0, wg_first = 0;   // SPEC: this workgroup's first chunk, and the image's first row of the tables
+    int jid;
+    if constexpr (SPEC) {
+        const dp_wg me = dp_wgs[blockIdx.x];
+        if (__builtin_amdgcn_readfirstlane(dp_flags[me.img]) != 3u) return;   // not a QOI-compat colour stream (pass 1 of decode_wave_kernel)
+        jid = dp_images[me.img].jid;
+        chunk_first = me.chunk0;
+        wg_first = dp_images[me.img].tab_off;
+    } else jid = job_ids[blockIdx.x];
     sqoa_hip_result* res = &results[jid];
     // Launched over every stream of the plan, after the SQOA kernel: a stream that kernel has decoded (or refused) costs this
     // workgroup one scalar load -- nothing is built, no barrier is met.  (Wave-uniform: every wave reads the same word, and
@@ -160,7 +187,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __syncthreads();
     if (!s_go) return;
     __syncthreads();
-    if (threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;
+    if (!SPEC && threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;   // (SPEC: the check behind this pass decides)
 
     const uint32_t hw = (uint32_t)src0[4] << 24 | (uint32_t)src0[5] << 16 | (uint32_t)src0[6] << 8 | src0[7];
     const uint32_t hh = (uint32_t)src0[8] << 24 | (uint32_t)src0[9] << 16 | (uint32_t)src0[10] << 8 | src0[11];
@@ -178,6 +205,18 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + QK_CHUNK - 1) / QK_CHUNK : 1;
     uint32_t bad = 0;
+    // SPEC: my own chunks [chunk_first, c_end), the warm-up [c_begin, chunk_first) in front of them; else the whole stream
+    const uint32_t c_begin = SPEC ? (chunk_first > dp_per ? chunk_first - dp_per : 0u) : 0u;
+    const uint32_t c_end = SPEC ? (chunk_first + dp_per < nchunks ? chunk_first + dp_per : nchunks) : nchunks;
+    if (SPEC && chunk_first >= nchunks) return;   // (the tables are laid out per 512 bytes of the longest chunk area; nothing here)
+    const dp_chunk_row* rows = SPEC ? dp_tab + wg_first : nullptr;
+    const uint32_t seed_st = SPEC && c_begin ? bcast_first(rows[c_begin / dp_per].st_in) : (uint32_t)ST_A;
+    const uint32_t seed_pos = SPEC && chunk_first ? bcast_first(rows[chunk_first / dp_per].pos_in) : 0u;
+    dq_state* my_dq = SPEC ? dq + 2 * (size_t)(wg_first + chunk_first / dp_per) : nullptr;   // [0]: at my first chunk, [1]: behind my last
+    // pad[0] of the row behind my last chunk counts the waves of this workgroup that came through without an error: the check wants all W
+    // (a workgroup that stops early must not leave the rows of an earlier launch standing)
+    if (SPEC && threadIdx.x == 0) __hip_atomic_store(&my_dq[1].pad[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
 
     // ================= the resolver: every chunk's serial section, in stream order ==========================================
     if (w == 0) {
@@ -190,7 +229,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #else
 #define RPH(k) do { } while (0)
 #endif
-        for (uint32_t c = 0; c < nchunks; ++c) {
+        for (uint32_t c = c_begin; c < c_end; ++c) {
+            if (SPEC && c == chunk_first) {   // the state my own chunks start from: exact (chunk 0) or what the warm-up arrived at
+                my_dq[0].px = pxv;
+                my_dq[0].tab[lane] = (uint32_t)__hip_atomic_load(&s_tab[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             uint32_t hopen = pxv;   // the pixel the segment that is open at a group's first op started from: the one entering the chunk, or an INDEX op's
             const uint32_t p = c % (uint32_t)P;
             uint32_t info = 0;
@@ -256,6 +299,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             RPH(5);
             qk_post(&s_done[p], c + 1, pxv, lane);
+        }
+        if (SPEC && !bad) {
+            my_dq[1].px = pxv;
+            my_dq[1].tab[lane] = (uint32_t)__hip_atomic_load(&s_tab[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) atomicAdd(&my_dq[1].pad[0], 1u);
         }
 #ifdef SQOA_QTRACE
         if (lane == 0) { unsigned long long* tr = (unsigned long long*)job.dst; for (int k = 0; k < 8; ++k) tr[k] = ph[k]; tr[6] = nchunks; }
@@ -327,22 +375,22 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         if (held == nchunks - 1) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             for (uint32_t k = held_out + lane; k < N; k += 64) put(k, pxv);
-            if (lane == 0) res->len = (int)(N * (uint32_t)oc);
+            if (!SPEC && lane == 0) res->len = (int)(N * (uint32_t)oc);
         }
         held = ~0u;
         return true;
     };
 
-    uint32_t c = p;
-    if (c < nchunks) load_chunk(c, stg);
-    for (; c < nchunks; c += P) {
+    uint32_t c = c_begin + (p + (uint32_t)P - c_begin % (uint32_t)P) % (uint32_t)P;   // my first chunk: c mod P == p
+    if (c < c_end) load_chunk(c, stg);
+    for (; c < c_end; c += P) {
         const bool last_chunk = c == nchunks - 1;
         // ---- stage the chunk's bytes (+ look-ahead); prefetch the wave's next chunk ----
         QP(0);
 #pragma unroll
         for (int k = 0; k < QK_NLD - 1; ++k) lds[lane + 64 * k] = stg[k];
         if (lane < QK_LDS_DW - 64 * (QK_NLD - 1)) lds[lane + 64 * (QK_NLD - 1)] = stg[QK_NLD - 1];
-        if (c + P < nchunks) load_chunk(c + P, stg);
+        if (c + P < c_end) load_chunk(c + P, stg);
         const uint32_t gs = p0 + c * QK_CHUNK;
         const uint32_t my0 = gs + QK_LB * lane;
         const uint32_t nlive = my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)QK_LB ? (uint32_t)QK_LB : chunks_len - my0);
@@ -367,8 +415,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         // safe because the position chain below holds a producer back: it cannot finish chunk c + P before chunk c + 1 was entered)
         unsigned long long* my_parse = &s_parse[(c / P) & 1][p];
         if (g_const && !last_chunk) qk_post(my_parse, c + 1, g0, lane);
-        uint32_t st_in = ST_A;
-        if (c > 0 && !qk_wait(&s_parse[((c - 1) / P) & 1][(c - 1) % P], c, st_in, bad)) break;
+        uint32_t st_in = seed_st;   // (the stream's start: A; SPEC: what the scan of pass 1 found in front of the warm-up's first chunk)
+        if (c > c_begin && !qk_wait(&s_parse[((c - 1) / P) & 1][(c - 1) % P], c, st_in, bad)) break;
         if (!g_const && !last_chunk) qk_post(my_parse, c + 1, apply(G, st_in), lane);
         const uint32_t lst = apply(Fx, st_in);
 
@@ -455,20 +503,73 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         // ---- pixel position: a plain sum, handed on at once ----
         QP(6);
         uint32_t pos_in = 0;
-        if (c > 0 && !qk_wait(&s_pos[(c - 1) % P], c, pos_in, bad)) break;
+        if (c > c_begin && !qk_wait(&s_pos[(c - 1) % P], c, pos_in, bad)) break;
+        if (SPEC && c == chunk_first) pos_in = seed_pos;   // (the warm-up's positions are dummies: nothing of it is stored)
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
         if (!last_chunk) qk_post(&s_pos[p], c + 1, pos_out, lane);
 
         // ---- over to the resolver (release: the records are in LDS when the tag is) ----
         QP(7);
         qk_post(&s_ready[p], c + 1, T | (pos_in < N ? 0u : 1u << 31), lane);
-        held = c; held_T = T; held_pos = pos_in; held_out = pos_out;
+        held = c; held_T = T; held_pos = SPEC && c < chunk_first ? N : pos_in; held_out = pos_out;
     }
     if (!bad) flush_held();
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+    if (SPEC && !bad && lane == 0) atomicAdd(&my_dq[1].pad[0], 1u);
 }
 
 }  // namespace sqoa
+
+namespace sqoa {
+// The check behind the speculative pass: one workgroup per image; thread k compares what workgroup k guessed for the state at its first
+// chunk with what workgroup k - 1 arrived at behind its last one.  All equal: the image is decoded (status OK, len); else it stays
+// SLOWPATH and the one-workgroup decoder, launched next, decodes it from the start.
+template <int W>
+__global__ __launch_bounds__(256) void dq_verify_kernel(const sqoa_hip_job* __restrict__ jobs, sqoa_hip_result* __restrict__ results,
+                                                        const dp_image* __restrict__ dp_images, const uint32_t* __restrict__ dp_flags,
+                                                        const dq_state* __restrict__ dq) {
+    __shared__ int s_bad;
+    const dp_image im = dp_images[blockIdx.x];
+    if (dp_flags[blockIdx.x] != 3u) return;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const dq_state* q = dq + 2 * (size_t)im.tab_off;
+    int bad = 0;
+    for (uint32_t k = threadIdx.x; k < im.nwgs; k += blockDim.x) {
+        if (q[2 * k + 1].pad[0] != (uint32_t)W) bad = 1;          // every wave of workgroup k came through
+        if (k == 0) continue;                                       // (the first workgroup starts from the stream's own initial state)
+        const dq_state& a = q[2 * k], & b = q[2 * (k - 1) + 1];
+        if (a.px != b.px) bad = 1;
+        for (int t = 0; t < 64; ++t) if (a.tab[t] != b.tab[t]) bad = 1;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_bad && results[im.jid].status == SQOA_HIP_ST_SLOWPATH) {
+        const sqoa_hip_job job = jobs[im.jid];
+        gcptr8 src = (gcptr8)job.src;
+        const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+        const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+        const uint32_t hc = src[12];
+        const uint32_t oc = job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u);
+        results[im.jid].len = (int)(hw * hh * oc);
+        results[im.jid].status = SQOA_HIP_ST_OK;
+    }
+}
+}  // namespace sqoa
+
+// The speculative chip-wide pass over the QOI-compat streams among a plan's few large streams, and the check behind it.
+extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
+                                                  const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
+                                                  hipStream_t stream) {
+    if (n_images <= 0 || n_wgs <= 0 || !d_qstate) return hipSuccess;
+    using namespace sqoa;
+    hipLaunchKernelGGL((decode_qoi_kernel<SQOA_QDEC_W, true>), dim3(n_wgs), dim3(SQOA_QDEC_W * 64), 0, stream, d_jobs, (const int*)nullptr, d_results,
+                       (const dp_image*)d_images, (const dp_wg*)d_wgs, (const dp_chunk_row*)d_tab, (const uint32_t*)d_flags, (dq_state*)d_qstate, per);
+    hipLaunchKernelGGL(dq_verify_kernel<SQOA_QDEC_W>, dim3(n_images), dim3(256), 0, stream, d_jobs, d_results, (const dp_image*)d_images, (const uint32_t*)d_flags,
+                       (const dq_state*)d_qstate);
+    return hipGetLastError();
+}
+extern "C" size_t sqoa_dq_state_bytes(void) { return 2 * sizeof(sqoa::dq_state); }   // per workgroup row of the tables
 
 // `small`: the plan's streams are short (many more images than the chip holds workgroups of the large shape)
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {

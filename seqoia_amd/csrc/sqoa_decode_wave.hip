@@ -128,7 +128,8 @@ __global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_state(const dp_image*
     __shared__ uint32_t s_lo[DP_SCAN_THREADS / 64], s_hi[DP_SCAN_THREADS / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const dp_image im = images[blockIdx.x];
-    if (flags[blockIdx.x] != 1u) return;
+    const uint32_t flag = flags[blockIdx.x];
+    if (flag != 1u && flag != 3u) return;
     dp_chunk* tab = tabs + im.tab_off;
     const uint32_t per = (im.nwgs + DP_SCAN_THREADS - 1) / DP_SCAN_THREADS;
     const uint32_t c0 = t * per < im.nwgs ? t * per : im.nwgs, c1 = c0 + per < im.nwgs ? c0 + per : im.nwgs;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_state(const dp_image*
     Fn P{ID_LO, ID_HI};
     for (uint32_t k = 0; k < wv; ++k) P = compose(Fn{s_lo[k], s_hi[k]}, P);
     const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
-    uint32_t st = apply(compose(Fx, P), ST_N);   // ST_N: stream start (seqoia.h:773-775)
+    uint32_t st = apply(compose(Fx, P), flag == 3u ? (uint32_t)ST_A : (uint32_t)ST_N);   // ST_N: stream start of an SQOA stream (seqoia.h:773-775)
     for (uint32_t c = c0; c < c1; ++c) {
         const Fn G{tab[c].g_lo, tab[c].g_hi};
         tab[c].st_in = st;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_pixels(const sqoa_hip
     __shared__ uint32_t s_c[DP_SCAN_THREADS / 64], s_v[DP_SCAN_THREADS / 64], s_a[DP_SCAN_THREADS / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const dp_image im = images[blockIdx.x];
-    if (flags[blockIdx.x] != 1u) return;
+    if (flags[blockIdx.x] != 1u && flags[blockIdx.x] != 3u) return;
     gcptr8 src = (gcptr8)jobs[im.jid].src;
     const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
     const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ uint32_t s_wg[3][MODE ? DP_CHUNKS_PER_WG_MAX : 1];   // passes 1 and 2: per chunk of the workgroup, what goes into its row
     uint32_t seed_st = ST_N, seed_pos = 0, seed_px = kPxInit;   // ST_N: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
     if (MODE >= 2 && chunk_first) seed_st = bcast_first(row->st_in);
+    else if (MODE >= 2 && bcast_first((uint32_t)src[14]) != 0x31u) seed_st = ST_A;   // (QOI-compat: the states are A, D1..D4, X)
     if (MODE == 3 && chunk_first) { seed_pos = bcast_first(row->pos_in); seed_px = bcast_first(row->px_in); }
 
     if (MODE >= 2 && threadIdx.x == 0) s_path = dp_flags[img];   // what pass 1 (or pass 2: SQOA_OP_REF) decided
@@ -282,17 +284,25 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         else {
             const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
             if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
-            else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }
+            else if (hc < 3 || q || oc < 3) {
+                res->status = SQOA_HIP_ST_SLOWPATH;
+                // (the chip-wide passes: a QOI-compat colour stream takes the speculative route of sqoa_decode_qoi.hip -- passes 1 and
+                // 2 here give it its chunks' parser states and pixel positions; the status stays SLOWPATH until that route has
+                // verified itself, so that the one-workgroup decoder picks the stream up if it has not)
+                path = (MODE == 1 && q && hc >= 3 && oc >= 3) ? 3u : 2u;
+            }
         }
         s_path = path;
         if (MODE == 1) dp_flags[img] = path;
     }
     if (MODE == 1 && chunk_first != 0 && threadIdx.x == 0) s_path = 1;  // (parsing bytes is harmless whatever the header says)
+    // QOI-compat framing (seqoia.h:677): no start byte, no ALPHA suffix -- another transition table, the chunk area one byte earlier
+    const bool qoi_stream = MODE != 0 && bcast_first((uint32_t)src[14]) != 0x31u;
     if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
     for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // transition function of a live byte (see header comment)
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
-        const uint32_t fA = (b0 - 0x60u) < 0x20u ? (uint32_t)ST_N : opn;
+        const uint32_t fA = (b0 - 0x60u) < 0x20u && !qoi_stream ? (uint32_t)ST_N : opn;
         s_ftab[b0] = fA | opn << 8 | 0x02000000u;
         // op decode of seqoia.h:740-775 as a table
         const bool is_abs = b0 >= 0xfeu, is_luma = (b0 & 0xc0u) == 0x80u, is_run = (b0 - 0xc0u) < 0x3eu, is_sfx = (b0 - 0x60u) < 0x20u;
@@ -309,7 +319,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     }
     if (threadIdx.x == 0) { u32x4 z = {4u << 3, 0u, 0u, 0u}; s_optab[256] = z; }
     __syncthreads();
-    if (s_path != 1) return;
+    // path 3 (QOI-compat, MODE 1 and 2 only): parsed and counted here, decoded by decode_qoi_kernel's speculative pass
+    if (s_path != 1 && !((MODE == 1 || MODE == 2) && s_path == 3)) return;
 
     const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
     const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
@@ -322,12 +333,20 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     const uint32_t soff = (uint32_t)(job.src & 3ull);
     gcptr8 srca = src - soff;
     const uint32_t size_a = size + soff;
-    const uint32_t p0 = kHeader + 1 + soff;     // first chunk byte (SQOA: after the start byte, seqoia.h:705)
+    const uint32_t p0 = kHeader + (qoi_stream ? 0u : 1u) + soff;     // first chunk byte (SQOA: after the start byte, seqoia.h:705)
     const uint32_t chunks_len = size_a - 8;     // seqoia.h:721
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + DEC_CHUNK - 1) / DEC_CHUNK : 1;
     // the chunks this workgroup takes: all of them, or (MODE > 0) dp_per from chunk_first on
     const uint32_t chunk_end = MODE == 0 ? nchunks : (chunk_first + dp_per < nchunks ? chunk_first + dp_per : nchunks);
+    if (MODE != 0 && chunk_first >= nchunks) {
+        // (the plan lays the tables out for the QOI-compat chunk area, one byte longer than the SQOA one: a workgroup past the end)
+        if (threadIdx.x == 0) {
+            if (MODE == 1) { row->g_lo = ID_LO; row->g_hi = ID_HI; }
+            if (MODE == 2) { row->ctot = 0; row->tv = 0; row->tabs = 0; }
+        }
+        return;
+    }
     uint32_t bad = 0;
 
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
@@ -443,6 +462,28 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
         // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
         const uint32_t lst = apply(Fx, st_in);  // parser state in front of my first byte
+        if constexpr (MODE == 2) {
+            if (qoi_stream) {
+                // QOI-compat stream: only the chunk's pixel count is wanted here (seqoia.h:740-775 with qoi_compat: every op is one
+                // pixel, a run byte 0xc0 | n -- 0xfd and 0xfc included -- is n + 1)
+                uint32_t qpos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u), qcl = 0;
+                const uint32_t qaddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u) + DEC_LB * lane;
+#pragma unroll
+                for (int i = 0; i < DEC_LB; ++i) {
+                    if (__ballot(qpos < nlive) == 0ull) break;
+                    const uint32_t a = qaddr + (qpos < (uint32_t)DEC_LB ? qpos : (uint32_t)DEC_LB);
+                    const uint32_t d0 = ((lcptr32)(uintptr_t)(a & ~3u))[0];
+                    const uint32_t b = (d0 >> ((a & 3u) * 8u)) & 0xffu;
+                    const uint32_t len = b >= 0xfeu ? b - 0xfau : ((b & 0xc0u) == 0x80u ? 2u : 1u);
+                    const uint32_t cnt = (b & 0xc0u) == 0xc0u && b < 0xfeu ? (b & 0x3fu) + 1u : 1u;
+                    if (qpos < nlive) { qcl += cnt; qpos += len; }
+                }
+                if (more) stage();
+                const uint32_t qtot = bcast_lane(wave_incl_scan(qcl), 63);
+                if (lane == 0) { s_wg[0][c - chunk_first] = qtot > N ? N : qtot; s_wg[1][c - chunk_first] = 0u; s_wg[2][c - chunk_first] = 0u; }
+                return 1u;
+            }
+        }
         // first op start: inside an op -> skip its remaining bytes; an ALPHA byte at an op boundary after an
         // op belongs to that op (whoever owns the op has read it), so it is skipped too
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u);
@@ -743,7 +784,7 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // full, more when it is (inside a workgroup the chunks are chained through LDS, and a short chain is mostly ramp-up: 1024
 // images at 16 chunks per workgroup 9.2 ms).  One table row per workgroup.
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size) {
-    const uint32_t area = src_size > 23u ? src_size - 23u : 0u;
+    const uint32_t area = src_size > 22u ? src_size - 22u : 0u;   // (the QOI-compat chunk area: one byte longer than the SQOA one -- no start byte)
     return area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
 }
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes) {

@@ -24,6 +24,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes);
+extern "C" size_t sqoa_dq_state_bytes(void);
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
 // empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
@@ -110,8 +111,8 @@ struct sqoa_hip_plan {
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
-    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
-    size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0;   // allocated rows
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
+    size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};   // encode: the few large images cut into strips
     int n_cut_sqoa = 0, n_cut_qoi = 0;   // how many at the front of the SQOA / QOI-compat id list they are
     size_t st_images_cap = 0, st_strips_cap = 0;
@@ -495,7 +496,8 @@ strips_done:
         if ((e = grow(&p->dp.d_flags, &p->dp_flags_cap, dp_images.size(), sizeof(uint32_t))) != hipSuccess ||
             (e = grow(&p->dp.d_images, &p->dp_images_cap, dp_images.size(), sizeof(dp_image_row))) != hipSuccess ||
             (e = grow(&p->dp.d_wgs, &p->dp_wgs_cap, dp_wgs.size(), sizeof(dp_wg_row))) != hipSuccess ||
-            (e = grow(&p->dp.d_tab, &p->dp_tab_cap, dp_rows, dp_row_bytes)) != hipSuccess) {
+            (e = grow(&p->dp.d_tab, &p->dp_tab_cap, dp_rows, dp_row_bytes)) != hipSuccess ||
+            (e = grow(&p->dp.d_qstate, &p->dp_qstate_cap, dp_rows, sqoa_dq_state_bytes())) != hipSuccess) {
             // (no memory for the tables: not an error -- the streams are decoded one workgroup each like the rest)
             (void)hipGetLastError();
             p->dp.n_images = p->dp.n_wgs = 0;
@@ -559,6 +561,7 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->dp.d_wgs) hipFree(p->dp.d_wgs);
     if (p->dp.d_tab) hipFree(p->dp.d_tab);
     if (p->dp.d_flags) hipFree(p->dp.d_flags);
+    if (p->dp.d_qstate) hipFree(p->dp.d_qstate);
     if (p->ev0) hipEventDestroy(p->ev0);
     if (p->ev1) hipEventDestroy(p->ev1);
     if (p->stream) hipStreamDestroy(p->stream);
