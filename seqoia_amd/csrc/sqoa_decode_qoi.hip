@@ -116,7 +116,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                                                                                    const dp_wg* __restrict__ dp_wgs = nullptr,
                                                                                                    const dp_chunk_row* __restrict__ dp_tab = nullptr,
                                                                                                    const uint32_t* __restrict__ dp_flags = nullptr,
-                                                                                                   dq_state* __restrict__ dq = nullptr, uint32_t dp_per = 0) {
+                                                                                                   dq_state* __restrict__ dq = nullptr, uint32_t dp_per = 0,
+                                                                                                   uint32_t dp_span = 1) {
     constexpr int P = W - 1;                       // producer waves; wave 0 is the resolver
     __shared__ uint32_t s_bytes[P][QK_LDS_DW];
     __shared__ uint32_t s_ftab[256];               // byte -> low half of its parser transition function
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         jid = dp_images[me.img].jid;
         chunk_first = me.chunk0;
         wg_first = dp_images[me.img].tab_off;
+        if ((chunk_first / dp_per) % dp_span != 0u) return;   // one workgroup per dp_span rows of the tables (sqoa_launch_decode_qoi_spec)
     } else jid = job_ids[blockIdx.x];
     sqoa_hip_result* res = &results[jid];
     // Launched over every stream of the plan, after the SQOA kernel: a stream that kernel has decoded (or refused) costs this
@@ -167,7 +169,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         s_go = go;
     }
     if (lane == 0 && w < P) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_ready[w] = 0; s_done[w] = 0; }
-    if (threadIdx.x < 64) s_tab[threadIdx.x] = 0;   // seqoia.h:712
+    // seqoia.h:712.  (SPEC, a warm-up that starts inside the stream: the entries are unknown there, and an INDEX op of the warm-up that
+    // reads one before anything has written it gets a pixel that is wrong whatever stands here -- but an opaque one is wrong in
+    // three channels, which the next RGB op repairs, and not in four, which only an RGBA op would: a 3-channel stream has none.)
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = SPEC && chunk_first > dp_per ? (unsigned long long)kPxInit : 0ull;
     for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {  // op lengths: fe 4, ff 5, 10xxxxxx 2, all others 1
         const uint32_t len = b0 >= 0xfeu ? b0 - 0xfau : ((b0 & 0xc0u) == 0x80u ? 2u : 1u);
         const uint32_t opn = len == 1u ? (uint32_t)ST_A : len;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     uint32_t bad = 0;
     // SPEC: my own chunks [chunk_first, c_end), the warm-up [c_begin, chunk_first) in front of them; else the whole stream
     const uint32_t c_begin = SPEC ? (chunk_first > dp_per ? chunk_first - dp_per : 0u) : 0u;
-    const uint32_t c_end = SPEC ? (chunk_first + dp_per < nchunks ? chunk_first + dp_per : nchunks) : nchunks;
+    const uint32_t c_end = SPEC ? (chunk_first + dp_span * dp_per < nchunks ? chunk_first + dp_span * dp_per : nchunks) : nchunks;
     if (SPEC && chunk_first >= nchunks) return;   // (the tables are laid out per 512 bytes of the longest chunk area; nothing here)
     const dp_chunk_row* rows = SPEC ? dp_tab + wg_first : nullptr;
     const uint32_t seed_st = SPEC && c_begin ? bcast_first(rows[c_begin / dp_per].st_in) : (uint32_t)ST_A;
@@ -222,7 +227,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (w == 0) {
         __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
         const unsigned long long bit = 1ull << lane, lt_mask = bit - 1ull;
-        uint32_t pxv = kPxInit;   // seqoia.h:716-719
+        // seqoia.h:716-719; SPEC, a warm-up that does not begin at the stream's start: pass 2's guess of the pixel there (decode_wave_kernel)
+        uint32_t pxv = SPEC && c_begin ? bcast_first(rows[c_begin / dp_per].px_in) : kPxInit;
+        [[maybe_unused]] unsigned long long rmask = 0;   // SPEC: index slots my own chunks read before writing them (per lane; OR-ed at the end)
 #ifdef SQOA_QTRACE  // diagnostic builds: where the resolver's time goes, written over the image's first pixels
         unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #define RPH(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
@@ -268,7 +275,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // final), in practice one round finds nothing to change -- where one INDEX op after the other cost a
                     // VALU -> SALU -> VALU round trip each.
                     RPH(2);
-                    const uint32_t tabv = isx ? (uint32_t)__hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                    const unsigned long long tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                    const uint32_t tabv = (uint32_t)tab64;
+                    unsigned long long earl = 0;   // SPEC: the group-internal writers of an INDEX op's slot, as of the last round
                     uint32_t X = tabv, val = 0, hv = 0;
                     RPH(3);
                     for (uint32_t round = 0; round <= ng; ++round) {
@@ -284,7 +293,13 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         const uint32_t Xn = earlier ? got : tabv;
                         const bool changed = isx && Xn != X;
                         X = Xn;
+                        earl = earlier;
                         if (__ballot(changed) == 0ull) break;
+                    }
+                    if constexpr (SPEC) {
+                        // an INDEX op of my OWN chunks that took its pixel from an index entry nothing of my own chunks has written yet:
+                        // the entry is the warm-up's guess -- the check must find it equal to the true one (dq_verify_kernel)
+                        if (c >= chunk_first && isx && earl == 0ull && (uint32_t)(tab64 >> 32) <= (chunk_first << 10)) rmask |= 1ull << slot;
                     }
                     RPH(4);
                     pxv = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(ng - 1u));
@@ -301,9 +316,18 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             qk_post(&s_done[p], c + 1, pxv, lane);
         }
         if (SPEC && !bad) {
+            const unsigned long long e = __hip_atomic_load(&s_tab[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             my_dq[1].px = pxv;
-            my_dq[1].tab[lane] = (uint32_t)__hip_atomic_load(&s_tab[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == 0) atomicAdd(&my_dq[1].pad[0], 1u);
+            my_dq[1].tab[lane] = (uint32_t)e;
+            const unsigned long long wmask = __ballot((uint32_t)(e >> 32) > (chunk_first << 10));   // slots my own chunks wrote
+            s_smask[0] = 0ull;
+            __hip_atomic_fetch_or(&s_smask[0], rmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long rm = __hip_atomic_load(&s_smask[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) {
+                my_dq[1].pad[1] = (uint32_t)rm; my_dq[1].pad[2] = (uint32_t)(rm >> 32);
+                my_dq[1].pad[3] = (uint32_t)wmask; my_dq[1].pad[4] = (uint32_t)(wmask >> 32);
+                atomicAdd(&my_dq[1].pad[0], 1u);
+            }
         }
 #ifdef SQOA_QTRACE
         if (lane == 0) { unsigned long long* tr = (unsigned long long*)job.dst; for (int k = 0; k < 8; ++k) tr[k] = ph[k]; tr[6] = nchunks; }
@@ -524,28 +548,114 @@ namespace sqoa {
 // The check behind the speculative pass: one workgroup per image; thread k compares what workgroup k guessed for the state at its first
 // chunk with what workgroup k - 1 arrived at behind its last one.  All equal: the image is decoded (status OK, len); else it stays
 // SLOWPATH and the one-workgroup decoder, launched next, decodes it from the start.
+#ifndef SQOA_DQ_MAX_SPAN
+#define SQOA_DQ_MAX_SPAN 64u
+#endif
+
+// The check behind the speculative pass.
+// Workgroup j's own chunks are decoded right if the pixel it started them from is the true one and every index entry they READ
+// before writing it (R_j) is the true one.  "True" is only known along the chain: V_j = the entries of workgroup j's END state
+// known to be true = the ones its own chunks wrote (W_j) plus the ones it guessed like the workgroup in front left them, where
+// those were known to be true:  V_0 = all,  good_j = eq_j & V_{j-1},  need R_j subset of good_j,  V_j = W_j | good_j.
+// (Entries nobody reads may differ: a slot last written far in front of the warm-up is simply stale in the guess.)
+//
+// dq_compare_kernel, one wave per workgroup of the speculative pass: eq_j (64 compares = one ballot), "the pixels agree" and
+// "every wave came through", left in the pad words of the workgroup's start row.
+SQOA_DEV uint32_t dq_nchunks(const sqoa_hip_job& job) {   // the stream's chunk count, as decode_qoi_kernel counts it
+    const uint32_t area = job.src_size > (uint32_t)kHeader + 8u ? job.src_size - (uint32_t)kHeader - 8u : 0u;
+    return area ? (area + QK_CHUNK - 1) / QK_CHUNK : 1u;
+}
 template <int W>
-__global__ __launch_bounds__(256) void dq_verify_kernel(const sqoa_hip_job* __restrict__ jobs, sqoa_hip_result* __restrict__ results,
-                                                        const dp_image* __restrict__ dp_images, const uint32_t* __restrict__ dp_flags,
-                                                        const dq_state* __restrict__ dq) {
-    __shared__ int s_bad;
-    const dp_image im = dp_images[blockIdx.x];
-    if (dp_flags[blockIdx.x] != 3u) return;
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
-    const dq_state* q = dq + 2 * (size_t)im.tab_off;
-    int bad = 0;
-    for (uint32_t k = threadIdx.x; k < im.nwgs; k += blockDim.x) {
-        if (q[2 * k + 1].pad[0] != (uint32_t)W) bad = 1;          // every wave of workgroup k came through
-        if (k == 0) continue;                                       // (the first workgroup starts from the stream's own initial state)
-        const dq_state& a = q[2 * k], & b = q[2 * (k - 1) + 1];
-        if (a.px != b.px) bad = 1;
-        for (int t = 0; t < 64; ++t) if (a.tab[t] != b.tab[t]) bad = 1;
+__global__ __launch_bounds__(512) void dq_compare_kernel(const sqoa_hip_job* __restrict__ jobs, const sqoa_hip_result* __restrict__ results,
+                                                         const dp_image* __restrict__ dp_images, const dp_wg* __restrict__ dp_wgs, uint32_t n_wgs,
+                                                         const uint32_t* __restrict__ dp_flags, dq_state* __restrict__ dq, uint32_t dp_per,
+                                                         uint32_t span) {
+    const uint32_t r = blockIdx.x * 8u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (r >= n_wgs) return;
+    const dp_wg me = dp_wgs[r];
+    if (dp_flags[me.img] != 3u) return;
+    const dp_image im = dp_images[me.img];
+    const uint32_t row = me.chunk0 / dp_per;
+    if (row % span != 0u || results[im.jid].status != SQOA_HIP_ST_SLOWPATH || me.chunk0 >= dq_nchunks(jobs[im.jid])) return;
+    dq_state* a = dq + 2 * (size_t)(im.tab_off + row);
+    uint32_t ok = a[1].pad[0] == (uint32_t)W ? 1u : 0u;
+    unsigned long long eq = ~0ull;
+    if (row) {
+        const dq_state* b = dq + 2 * (size_t)(im.tab_off + row - span) + 1;
+        eq = __ballot(a[0].tab[lane] == b->tab[lane]);
+        if (a[0].px != b->px) ok |= 2u;
     }
-    if (bad) s_bad = 1;
+    if (lane == 0) { a[0].pad[5] = (uint32_t)eq; a[0].pad[6] = (uint32_t)(eq >> 32); a[0].pad[7] = ok; }
+}
+
+// dq_verify_kernel, one workgroup per stream: the chain as a scan.  V_j = W_j | (eq_j & V_{j-1}) is, per bit, one of "0", "1",
+// "as before" -- functions that compose: (A, B): v -> A | (B & v), then (A', B') gives (A' | (B' & A), B' & B).  Every thread
+// composes a contiguous run of workgroups, the run totals are scanned through LDS, the runs are walked again for the subset test.
+__global__ __launch_bounds__(1024) void dq_verify_kernel(const sqoa_hip_job* __restrict__ jobs, sqoa_hip_result* __restrict__ results,
+                                                         const dp_image* __restrict__ dp_images, const uint32_t* __restrict__ dp_flags,
+                                                         const dq_state* __restrict__ dq, uint32_t dp_per, uint32_t span) {
+    __shared__ unsigned long long s_a[2][1024], s_b[2][1024];
+    __shared__ uint32_t s_bad;
+    const dp_image im = dp_images[blockIdx.x];
+    if (dp_flags[blockIdx.x] != 3u || results[im.jid].status != SQOA_HIP_ST_SLOWPATH) return;   // (block-uniform; nothing here writes it before the end)
+    const sqoa_hip_job job = jobs[im.jid];
+    const uint32_t nrows = (dq_nchunks(job) + dp_per - 1) / dp_per, nj = (nrows + span - 1) / span;
+    const uint32_t t = threadIdx.x, per = (nj + 1023u) / 1024u;
+    const uint32_t j0 = t * per < nj ? t * per : nj, j1 = j0 + per < nj ? j0 + per : nj;
+    const dq_state* q = dq + 2 * (size_t)im.tab_off;
+    if (t == 0) s_bad = 0;
+#ifdef SQOA_DQ_DEBUG
+    if (t == 0) results[im.jid].len = 0x7fffffff;
+#endif
+    unsigned long long A = 0ull, B = ~0ull;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const dq_state* e = q + 2 * (size_t)j * span;
+        const unsigned long long eq = (unsigned long long)e[0].pad[6] << 32 | e[0].pad[5], wm = (unsigned long long)e[1].pad[4] << 32 | e[1].pad[3];
+        A = wm | (eq & A); B = eq & B;
+    }
+    s_a[0][t] = A; s_b[0][t] = B;
     __syncthreads();
-    if (threadIdx.x == 0 && !s_bad && results[im.jid].status == SQOA_HIP_ST_SLOWPATH) {
-        const sqoa_hip_job job = jobs[im.jid];
+    int cur = 0;
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the run totals
+        unsigned long long a2 = s_a[cur][t], b2 = s_b[cur][t];
+        if (t >= d) { const unsigned long long a1 = s_a[cur][t - d], b1 = s_b[cur][t - d]; a2 = a2 | (b2 & a1); b2 = b2 & b1; }
+        s_a[cur ^ 1][t] = a2; s_b[cur ^ 1][t] = b2;
+        cur ^= 1;
+        __syncthreads();
+    }
+    // V in front of my run: the prefix applied to "all" (workgroup 0 starts from the stream's true start state)
+    unsigned long long v = t ? s_a[cur][t - 1] | s_b[cur][t - 1] : ~0ull;
+    uint32_t bad = 0;
+    [[maybe_unused]] uint32_t why = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const dq_state* e = q + 2 * (size_t)j * span;
+        const unsigned long long eq = (unsigned long long)e[0].pad[6] << 32 | e[0].pad[5], wm = (unsigned long long)e[1].pad[4] << 32 | e[1].pad[3];
+        const unsigned long long rm = (unsigned long long)e[1].pad[2] << 32 | e[1].pad[1];
+        const unsigned long long good = eq & v;
+        const uint32_t ok = e[0].pad[7];
+        if (ok != 1u || (rm & ~good)) {
+#ifdef SQOA_DQ_DEBUG
+            if (!bad) why = j * 16u + ((ok & 1u) ? 0u : 1u) + ((rm & ~good) ? 2u : 0u) + ((rm & ~eq) ? 4u : 0u) + ((ok & 2u) ? 8u : 0u);
+#endif
+            bad = 1;
+        }
+        v = wm | good;
+    }
+    if (bad) {
+#ifdef SQOA_DQ_DEBUG   // diagnostic builds: the first workgroup that fails and why, instead of the fall-back
+        atomicMin((uint32_t*)&results[im.jid].len, why);
+#endif
+        s_bad = 1;
+    }
+    __syncthreads();
+#ifdef SQOA_DQ_DEBUG
+    if (t == 0 && s_bad) results[im.jid].status = SQOA_HIP_ST_BADARG;
+#endif
+#ifdef SQOA_DQ_ACCEPT_ALL   // mutation builds (tests/README: the stale-entry tests must FAIL with this)
+    if (t == 0) {
+#else
+    if (t == 0 && !s_bad) {
+#endif
         gcptr8 src = (gcptr8)job.src;
         const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
         const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
@@ -563,10 +673,27 @@ extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sq
                                                   hipStream_t stream) {
     if (n_images <= 0 || n_wgs <= 0 || !d_qstate) return hipSuccess;
     using namespace sqoa;
+    // A workgroup decodes `span` rows of the tables behind one row of warm-up: as few rows as fill the chip's workgroup slots once
+    // (the warm-up is work thrown away: at one row each, half of everything).
+    static int cus = 0;   // (one kind of device per process)
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    const unsigned slots = (unsigned)cus * 4u;
+    const unsigned span = ((unsigned)n_wgs + slots - 1) / slots;
+    // A guess that fails (content that lives on INDEX ops: entries written once, read for ever) has cost this pass on top of the
+    // one-workgroup decode that then does the work.  1024 x 1024 images, tools/time_single_qoi_decode.py: one 0.094 against
+    // 8.7 ms, 16: 0.62 / 9.3, 64: 2.0 / 9.4, 256: 6.6 / 9.5 ms -- from SQOA_DQ_MAX_SPAN rows per workgroup on there is little to
+    // win and as much to lose: those plans go straight to the one-workgroup decoder.
+    if (span > SQOA_DQ_MAX_SPAN) return hipSuccess;
     hipLaunchKernelGGL((decode_qoi_kernel<SQOA_QDEC_W, true>), dim3(n_wgs), dim3(SQOA_QDEC_W * 64), 0, stream, d_jobs, (const int*)nullptr, d_results,
-                       (const dp_image*)d_images, (const dp_wg*)d_wgs, (const dp_chunk_row*)d_tab, (const uint32_t*)d_flags, (dq_state*)d_qstate, per);
-    hipLaunchKernelGGL(dq_verify_kernel<SQOA_QDEC_W>, dim3(n_images), dim3(256), 0, stream, d_jobs, d_results, (const dp_image*)d_images, (const uint32_t*)d_flags,
-                       (const dq_state*)d_qstate);
+                       (const dp_image*)d_images, (const dp_wg*)d_wgs, (const dp_chunk_row*)d_tab, (const uint32_t*)d_flags, (dq_state*)d_qstate, per, span);
+    hipLaunchKernelGGL(dq_compare_kernel<SQOA_QDEC_W>, dim3((n_wgs + 7) / 8), dim3(512), 0, stream, d_jobs, (const sqoa_hip_result*)d_results,
+                       (const dp_image*)d_images, (const dp_wg*)d_wgs, (uint32_t)n_wgs, (const uint32_t*)d_flags, (dq_state*)d_qstate, per, span);
+    hipLaunchKernelGGL(dq_verify_kernel, dim3(n_images), dim3(1024), 0, stream, d_jobs, d_results, (const dp_image*)d_images, (const uint32_t*)d_flags,
+                       (const dq_state*)d_qstate, per, span);
     return hipGetLastError();
 }
 extern "C" size_t sqoa_dq_state_bytes(void) { return 2 * sizeof(sqoa::dq_state); }   // per workgroup row of the tables

@@ -466,21 +466,39 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             if (qoi_stream) {
                 // QOI-compat stream: only the chunk's pixel count is wanted here (seqoia.h:740-775 with qoi_compat: every op is one
                 // pixel, a run byte 0xc0 | n -- 0xfd and 0xfc included -- is n + 1)
+                // ... and a GUESS of the pixel entering every workgroup's range, for the speculative pass to start its warm-up from:
+                // the ops' transforms composed as for an SQOA stream, an INDEX op -- whose pixel only the decoder state knows --
+                // taken as "no change".  Exact wherever no INDEX op stands between the last RGB / RGBA op and the range (smooth
+                // content is DIFF / LUMA ops for kilobytes on end: nothing in a warm-up would ever anchor the pixel); where it
+                // is wrong, the check behind the speculative pass finds out (dq_verify_kernel).
                 uint32_t qpos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u), qcl = 0;
                 const uint32_t qaddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u) + DEC_LB * lane;
+                Xf QT{0u, 0u};
 #pragma unroll
                 for (int i = 0; i < DEC_LB; ++i) {
                     if (__ballot(qpos < nlive) == 0ull) break;
                     const uint32_t a = qaddr + (qpos < (uint32_t)DEC_LB ? qpos : (uint32_t)DEC_LB);
-                    const uint32_t d0 = ((lcptr32)(uintptr_t)(a & ~3u))[0];
-                    const uint32_t b = (d0 >> ((a & 3u) * 8u)) & 0xffu;
+                    lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+                    const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                    const uint32_t b = lo & 0xffu, b1 = (lo >> 8) & 0xffu;
                     const uint32_t len = b >= 0xfeu ? b - 0xfau : ((b & 0xc0u) == 0x80u ? 2u : 1u);
                     const uint32_t cnt = (b & 0xc0u) == 0xc0u && b < 0xfeu ? (b & 0x3fu) + 1u : 1u;
-                    if (qpos < nlive) { qcl += cnt; qpos += len; }
+                    const uint32_t vg = (b & 0x3fu) - 32u;
+                    Xf op{0u, 0u};
+                    if (b == 0xfeu) op = Xf{(lo >> 8) & 0x00ffffffu, 0x00ffffffu};                      // seqoia.h:741-745
+                    else if (b == 0xffu) op = Xf{lo >> 8 | hi << 24, 0xffffffffu};                      // seqoia.h:746-751
+                    else if ((b & 0xc0u) == 0x40u)                                                      // seqoia.h:756-760
+                        op.v = ((((b >> 4) & 3u) - 2u) & 0xffu) | ((((b >> 2) & 3u) - 2u) & 0xffu) << 8 | (((b & 3u) - 2u) & 0xffu) << 16;
+                    else if ((b & 0xc0u) == 0x80u)                                                      // seqoia.h:761-769
+                        op.v = ((vg - 8u + (b1 >> 4)) & 0xffu) | (vg & 0xffu) << 8 | ((vg - 8u + (b1 & 15u)) & 0xffu) << 16;
+                    if (qpos < nlive) { qcl += cnt; qpos += len; QT = xf_then(QT, op); }
                 }
                 if (more) stage();
                 const uint32_t qtot = bcast_lane(wave_incl_scan(qcl), 63);
-                if (lane == 0) { s_wg[0][c - chunk_first] = qtot > N ? N : qtot; s_wg[1][c - chunk_first] = 0u; s_wg[2][c - chunk_first] = 0u; }
+                const Xf QTi = wave_xf_scan(QT);
+                const uint32_t qv = bcast_lane(QTi.v, 63), qa = bcast_lane(QTi.abs, 63);
+                if (lane == 0) { s_wg[0][c - chunk_first] = qtot > N ? N : qtot; s_wg[1][c - chunk_first] = qv; s_wg[2][c - chunk_first] = qa; }
                 return 1u;
             }
         }

@@ -490,11 +490,12 @@ def test_batch_decode_random_bodies_match_oracle(sq, orc, route):
             dec.close()
 
 
-def test_qoi_long_random_streams_match_oracle(sq, orc):
+def test_qoi_long_random_streams_match_oracle(sq, orc, route):
     """QOI-compat bodies of random ops over dozens of 512-byte steps: INDEX ops (a quarter of random bytes) at every
     position of the 64-op groups and across step boundaries, look-ups of slots nobody has written, runs that pass the
     end of the image.  The wave-parallel QOI decoder (segmented transform scan + stamped index updates) must agree with
-    the reference byte for byte."""
+    the reference byte for byte -- one workgroup per stream, and on the speculative chip-wide route (`route` = "1"), whose
+    guessed decoder states are mostly WRONG on such bodies: its check must find every one of them."""
     import torch
 
     o = orc.best()
@@ -683,3 +684,116 @@ def test_waveonly_jobs_skip_the_other_decoders_and_hand_back_what_they_cannot_ta
     bad.launch()
     assert bad.results()["status"][0] == 1
     bad.close()
+
+
+def _qoi_stream(w, h, ch, ops):
+    return b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + b"".join(ops) + bytes(7) + b"\x01"
+
+
+def _qoi_hash(r, g, b, a=255):
+    return (r * 3 + g * 5 + b * 7 + a * 11) % 64   # seqoia.h:785-787 (qoi_compat)
+
+
+def test_speculative_qoi_route_finds_stale_index_entries(sq, orc, monkeypatch):
+    """The speculative chip-wide QOI-compat decode (decode_qoi_kernel<8, SPEC> + dq_compare_kernel + dq_verify_kernel) guesses the
+    colour index in front of every workgroup's range from the 4 KiB before it.  Streams built so that the guess is wrong in exactly
+    the ways the check has to catch: an entry written once at the stream's start and read far behind it (never inside any warm-up);
+    the same with the entry rewritten to ANOTHER colour two ranges before the read (the warm-up misses the write that counts); an
+    entry read through a DIFF chain that starts from it; and the harmless twin of each (entry rewritten inside the warm-up), which
+    the route may accept.  Whatever it decides, the pixels are the reference's."""
+    import torch
+
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", "1")
+    o = orc.best()
+    rng = np.random.default_rng(31)
+    w = h = 256
+    N = w * h
+    key = (200, 100, 50)
+    slot = _qoi_hash(*key)
+    other = next((r, 7, 9) for r in range(256) if _qoi_hash(r, 7, 9) == slot and (r, 7, 9) != key)
+
+    def rgb(c):
+        return bytes([0xfe, c[0], c[1], c[2]])
+
+    def noise(n):   # literal pixels that never touch `slot`
+        out = []
+        while len(out) < n:
+            c = tuple(int(x) for x in rng.integers(0, 256, size=3))
+            if _qoi_hash(*c) != slot:
+                out.append(rgb(c))
+        return out
+
+    streams = []
+    for variant in range(6):
+        ops = [rgb(key)]
+        fill = N - 1
+        if variant == 0:     # read at the very end
+            ops += noise(fill - 1) + [bytes([slot])]
+        elif variant == 1:   # read every 3000 pixels
+            body = noise(fill)
+            for k in range(2999, fill, 3000):
+                body[k] = bytes([slot])
+            ops += body
+        elif variant == 2:   # rewritten to another colour, read 2500 ops (10 000 bytes: more than a warm-up) later
+            body = noise(fill)
+            body[20000] = rgb(other)
+            body[22500] = bytes([slot])
+            ops += body
+        elif variant == 3:   # a DIFF chain behind the stale read, then an INDEX op on what the chain wrote
+            body = noise(fill)
+            body[30000] = bytes([slot])
+            for k in range(30001, 30040):
+                body[k] = bytes([0x40 | 0x3f])   # +1 +1 +1
+            ops += body
+        elif variant == 4:   # the harmless twin of 2: rewritten 100 ops in front of the read
+            body = noise(fill)
+            body[22400] = rgb(other)
+            body[22500] = bytes([slot])
+            ops += body
+        else:                # no literal pixels at all behind the first: DIFF / LUMA ops and reads of the one entry
+            body = [bytes([0x40 | int(x)]) for x in rng.integers(0, 64, size=fill)]
+            for k in range(4999, fill, 5000):
+                body[k] = bytes([slot])
+            ops += body
+        streams.append(_qoi_stream(w, h, 3, ops))
+    slotb = max(len(s) for s in streams) + 32
+    buf = np.zeros((len(streams), slotb), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    dev = torch.from_numpy(buf).cuda()
+    for oc in (3, 4):
+        dec = sq.DecodePlan(dev, [len(s) for s in streams], w, h, oc)
+        dec.launch()
+        res = dec.results()
+        out = dec.out.cpu().numpy()
+        for i, s in enumerate(streams):
+            want = o.decode(s, oc)[0]
+            assert res["status"][i] == 0 and res["len"][i] == N * oc, (oc, i)
+            assert out[i].tobytes() == want.tobytes(), (oc, i)
+        dec.close()
+
+
+@pytest.mark.parametrize("cls,ch", [("mixed", 4), ("mixed", 3), ("photo", 3)])
+def test_lone_large_qoi_stream_is_decoded_by_the_whole_chip(sq, orc, cls, ch):
+    """One 1024 x 1024 QOI-compat stream alone in a plan: the plan's own choice is the speculative chip-wide route, and on
+    photo-like content its guesses hold -- visible as time: one workgroup needs 8.7 ms for such a stream (one compute unit's
+    instruction issue), the chip 0.1 ms; a failed guess would cost both.  Pixels against the reference's decode of the same stream."""
+    import torch
+
+    w = h = 1024
+    px = torch.empty((1, h, w, ch), dtype=torch.uint8, device="cuda")
+    sq.synth(px, cls, seed=9, img0=2)
+    enc = sq.EncodePlan(px, qoi_compat=1)
+    enc.launch()
+    res = enc.results()
+    assert res["status"][0] == 0
+    dec = sq.DecodePlan(enc.out, res["len"], w, h, ch)
+    dec.launch()
+    assert dec.results()["status"][0] == 0
+    want = orc.best().decode(enc.streams()[0], ch)[0]
+    assert dec.out[0].cpu().numpy().tobytes() == want.tobytes()
+    dec.time(3)
+    ms = min(dec.time(3) / 3 for _ in range(3))
+    assert ms < 2.0, ms
+    dec.close()
+    enc.close()
