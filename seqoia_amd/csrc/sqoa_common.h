@@ -26,6 +26,7 @@ struct sqoa_dp_tables {
     void* d_tab;                    // dp_chunk rows: one per chunk
     void* d_flags;                  // one word per image, written by pass 1: 1 wave path, 2 left to the other kernels, 3 QOI-compat colour stream: speculative pass
     void* d_qstate;                 // two decoder states (pixel + colour index, 512 bytes each) per workgroup row: the speculative pass of QOI-compat streams
+    int any_qoi;                    // a HINT, taken when the plan was filled: some of these streams are in QOI-compat framing (0: the speculative pass and its check are not launched)
 };
 
 // Tables of the strip encode of few large images (sqoa_strips.hip); built by the plan (sqoa_runtime.hip).

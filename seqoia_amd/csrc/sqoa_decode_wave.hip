@@ -796,6 +796,26 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
     return hipGetLastError();
 }
 
+// Does any of the multi-pass streams use the QOI-compat framing (seqoia.h:677)?  Asked once when the plan is filled, so that plans
+// without one do not launch the speculative pass and its two checks for nothing (three launches that leave on one load each are
+// still 8 us of a lone stream's 0.10 ms).  Only a hint: a stream the plan does not launch them for stays SLOWPATH and is decoded
+// by the one-workgroup kernel behind.
+namespace sqoa {
+__global__ void dp_classify_kernel(const sqoa_hip_job* __restrict__ jobs, const dp_image* __restrict__ images, int n, uint32_t* __restrict__ word) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const sqoa_hip_job job = jobs[images[i].jid];
+    if (job.src_size > (uint32_t)kHeader && ((gcptr8)job.src)[kHeader] != 0x31u) atomicOr(word, 1u);
+}
+}  // namespace sqoa
+extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const void* d_images, int n_images, void* d_word, hipStream_t stream) {
+    if (n_images <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_word, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sqoa::dp_classify_kernel, dim3((n_images + 255) / 256), dim3(256), 0, stream, d_jobs, (const sqoa::dp_image*)d_images, n_images, (uint32_t*)d_word);
+    return hipGetLastError();
+}
+
 // What the plan needs to lay the pass tables out (sqoa_runtime.hip): the chunks of a stream of `src_size` bytes (the chunk area is
 // what lies between header + start byte and the 8 end bytes, as in decode_wave_kernel), and -- for `total_chunks` over all the
 // multi-pass streams of a plan -- how many chunks a workgroup of a pass takes: few (many workgroups) while the chip is not

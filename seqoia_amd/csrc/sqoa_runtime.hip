@@ -25,6 +25,7 @@ extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes);
 extern "C" size_t sqoa_dq_state_bytes(void);
+extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const void* d_images, int n_images, void* d_word, hipStream_t stream);
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
 // empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
@@ -111,7 +112,7 @@ struct sqoa_hip_plan {
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
-    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr};   // decode: the few large streams that take the three-pass route
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};   // encode: the few large images cut into strips
     int n_cut_sqoa = 0, n_cut_qoi = 0;   // how many at the front of the SQOA / QOI-compat id list they are
@@ -507,6 +508,16 @@ strips_done:
             (e = hipMemcpy(p->dp.d_wgs, dp_wgs.data(), sizeof(dp_wg_row) * dp_wgs.size(), hipMemcpyHostToDevice)) != hipSuccess) {
             p->dp.n_images = p->dp.n_wgs = 0;
             return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the multi-pass decode, upload", e);
+        }
+        // which framing do these streams use?  (one byte of each, read where they lie; the flag words are free until pass 1 writes them)
+        uint32_t any = 1;
+        p->dp.any_qoi = 1;
+        if (!p->wave_only) {
+            if (sqoa_launch_dp_classify(p->d_jobs, p->dp.d_images, p->dp.n_images, p->dp.d_flags, p->stream) == hipSuccess &&
+                hipMemcpyAsync(&any, p->dp.d_flags, sizeof any, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
+                hipStreamSynchronize(p->stream) == hipSuccess)
+                p->dp.any_qoi = any != 0;
+            else (void)hipGetLastError();
         }
     }
     return 0;
