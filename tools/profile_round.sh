@@ -3,7 +3,7 @@
 # bench line + rocprofv3 kernel stats (20 warm-up + 20 timed steps, so that AverageNs is a warm average) + separate PMC
 # passes (HBM bytes, SQ issue counters, LDS busy / bank-conflict cycles) of the headline batch; then the same kernel stats
 # + SQ + LDS passes for the QOI-compat kernels on the headline batch and for the RGB icon batch (BASELINE configs[3]) in
-# both wire formats -> gpurun_out/TAG_*   (copy what is to be judged into profiles/)
+# both wire formats, and the kernel stats of one large QOI-compat stream alone -> gpurun_out/TAG_*   (copy what is to be judged into profiles/)
 set -e
 tag=$1
 out=gpurun_out
@@ -30,4 +30,8 @@ sec() {   # sec NAME prof_kernels-args...
 sec qoi --images 1024 --qoi 1
 sec icons --images 4096 --size 512 --channels 3 --cls icon --qoi 0
 sec icons_qoi --images 4096 --size 512 --channels 3 --cls icon --qoi 1
+# one large QOI-compat stream alone (2880 x 2880 = the pixels of 3840 x 2160): the chip-wide routes -- strips for the encode,
+# passes 1 and 2 + the speculative pass + its check for the decode; kernel stats only
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof_${tag}_lone_qoi -o run -- python3 tools/prof_kernels.py --iters 10 --images 1 --size 2880 --qoi 1 > $out/${tag}_lone_qoi_prof.log 2>&1
+find $out/prof_${tag}_lone_qoi -name "*kernel_stats.csv" -exec cp {} $out/${tag}_lone_qoi_kernel_stats.csv \;
 cat $out/${tag}_bench.json; head -8 $out/${tag}_kernel_stats.csv
