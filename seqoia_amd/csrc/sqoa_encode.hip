@@ -1390,7 +1390,25 @@ extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const i
 #define SQOA_ENC_W 8
 #endif
     constexpr int W = SQOA_ENC_W;
-    if (qoi) hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
+    // QOI-compat: 112 VGPRs and 76 KB of LDS per eight-wave workgroup make that two images per CU.  From more images than that
+    // on, four waves per image and four images per CU -- the same 16 waves -- do better: the colour index is a serial chain
+    // through an image's sub-tiles, and twice the images in flight hide more of it (1024 x 1024 x 1024 RGBA 3.05 -> 2.97 ms,
+    // 4096 icons of 512 x 512 RGB 3.10 -> 2.93 ms; two waves per image: 4.6 / 3.9 ms).  Fewer images than 2 per CU, and
+    // strips (a workgroup per CU-sized piece of one image): eight waves (256 images 1.37 against 1.98 ms).
+    if (qoi) {
+        static int cus = 0;   // (one kind of device per process)
+        if (!cus) {
+            int dev = 0, k = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&k, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || k <= 0) k = 256;
+            cus = k;
+        }
+#ifndef SQOA_ENC_W_QOI_MANY
+#define SQOA_ENC_W_QOI_MANY 4
+#endif
+        constexpr int WM = SQOA_ENC_W_QOI_MANY;
+        if (!d_qtab_in && n > 2 * cus) hipLaunchKernelGGL((encode_kernel<WM, true>), dim3(n), dim3(WM * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
+        else hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
+    }
     else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
