@@ -545,12 +545,22 @@ def run_rank(args):
             graph = None
 
     # The device has been idle while the CPU baseline and the setup ran, and the first ~50 ms of work after an idle period run at
-    # lower clocks (tools/time_warm.py): untimed steps until 0.15 s have gone by, then the W warm-up steps the caller asked for.
-    spin_up, t_spin = 0, time.perf_counter()
-    while time.perf_counter() - t_spin < 0.15 and spin_up < 64:
-        run()
+    # lower clocks (tools/time_warm.py): untimed steps for at least 0.15 s, then the W warm-up steps the caller asked for.
+    # A cold box can take longer (profiles/r03_d_bench.json: 28 spin-up steps at 5.4 ms, then a timed region at 5.27 ms while the
+    # kernels measured right after it ran at their usual 1.54 + 3.46 ms): go on in groups of 8 until a group is no faster than the
+    # one before it (within 1.5 %), 1.5 s at most.
+    spin_up, t_spin, prev_group = 0, time.perf_counter(), None
+    while True:
+        t_g = time.perf_counter()
+        for _ in range(8):
+            run()
         torch.cuda.synchronize()
-        spin_up += 1
+        spin_up += 8
+        group = time.perf_counter() - t_g
+        gone = time.perf_counter() - t_spin
+        if gone > 1.5 or (gone >= 0.15 and prev_group is not None and group > 0.985 * prev_group):
+            break
+        prev_group = group
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
