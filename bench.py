@@ -155,6 +155,7 @@ def cpu_worker(arg):
 
     t, per, width, height, channels = (int(x) for x in arg.split(",")[:5])
     start = float(arg.split(",")[5])
+    rounds = int(arg.split(",")[6]) if len(arg.split(",")) > 6 else 1
     codec = po.best()
     dl, nl, ddl = po.Desc(width, height, channels, 0, 0), C.c_int(0), po.Desc()
     imgs = [po.synth(width, height, channels, "mixed", 1, t * per + k) for k in range(per)]
@@ -163,14 +164,15 @@ def cpu_worker(arg):
     while time.time() < start:  # every core enters the timed loop together
         time.sleep(0.001)
     t0 = time.time()
-    for p, e in zip(imgs, encs):
-        a = time.perf_counter()
-        codec.encode_raw(p.ctypes.data, C.byref(dl), C.byref(nl))
-        b = time.perf_counter()
-        codec.decode_raw(e, len(e), C.byref(ddl), 4)
-        c = time.perf_counter()
-        te += b - a
-        td += c - b
+    for _ in range(rounds):
+        for p, e in zip(imgs, encs):
+            a = time.perf_counter()
+            codec.encode_raw(p.ctypes.data, C.byref(dl), C.byref(nl))
+            b = time.perf_counter()
+            codec.decode_raw(e, len(e), C.byref(ddl), 4)
+            c = time.perf_counter()
+            te += b - a
+            td += c - b
     print(json.dumps([te, td, t0, time.time()]))
 
 
@@ -217,9 +219,11 @@ def cpu_baseline(width, height, channels):
     # buffer in every call (seqoia.h:492, :710), and threads of one process serialise on the address-space lock for those
     # mmap / munmap / page-fault cycles (128 threads: 36 / 44 Mpixels/s per core against 332 / 388 alone).  Plain child
     # processes with a common start time, each waited for with a time-out: nothing here can hang the benchmark.
-    per_thread = 8  # images per worker: encode + decode of a 1 Mpixel image ~6 ms alone, so a fraction of a second of timed work each
+    # images per worker and passes over them: encode + decode of a 1 Mpixel image ~6 ms alone, so ~0.8 s of timed work per worker,
+    # ~12 core-seconds on 16 cores (8 images once, 50 ms, was at the mercy of the workers' start skew: 1 590 .. 2 700 Mpixels/s)
+    per_thread, rounds = 8, max(1, int(16 * (1 << 20) / px_img))
     start = time.time() + 2.0 + 0.03 * cores  # interpreter start + synthesis of every worker's images fit in front of it
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t},{per_thread},{width},{height},{channels},{start}"],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t},{per_thread},{width},{height},{channels},{start},{rounds}"],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for t in range(cores)]
     parts = []
     for pr in procs:
@@ -237,7 +241,7 @@ def cpu_baseline(width, height, channels):
     late = sum(1 for p in parts if p[2] > start + 0.05)
     cores_used = len(parts)
     busy = max(p[3] for p in parts) - min(p[2] for p in parts)  # from the common start to the last worker's last call (time.time: one clock for all)
-    px_total = cores_used * per_thread * px_img
+    px_total = cores_used * per_thread * rounds * px_img
     return {
         "value": round(px_total / busy / 1e6, 1),
         "unit": "Mpixels/s",
@@ -246,9 +250,9 @@ def cpu_baseline(width, height, channels):
         "cpu_quota": quota,
         "logical_cpus": logical,
         "kind": codec.kind,
-        "sample": f"{cores_used * per_thread} distinct images {width}x{height}x{channels} (class mixed, seed 1), encode+decode each, {cores_used} worker processes (one per physical core)",
-        "encode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[0] for p in parts) / cores_used) / 1e6, 1),
-        "decode_mpps_per_core_under_load": round(per_thread * px_img / (sum(p[1] for p in parts) / cores_used) / 1e6, 1),
+        "sample": f"{cores_used * per_thread} distinct images {width}x{height}x{channels} (class mixed, seed 1), encode+decode each, {rounds} passes, {cores_used} worker processes (one per physical core)",
+        "encode_mpps_per_core_under_load": round(per_thread * rounds * px_img / (sum(p[0] for p in parts) / cores_used) / 1e6, 1),
+        "decode_mpps_per_core_under_load": round(per_thread * rounds * px_img / (sum(p[1] for p in parts) / cores_used) / 1e6, 1),
         "single_thread": single,
     }
 
