@@ -399,14 +399,19 @@ def test_plans_replay_from_a_hip_graph(sq, orc):
     dec.close()
     # the decode plan in a graph of its own, on both routes of the wave decoder (the three-pass route is five kernels and two
     # scan kernels per launch, all of them captured)
+    # (and, from QOI-compat streams, the speculative route: passes 1 and 2, the speculative pass, its two checks, the stand-by kernels)
     import os
     sq.synth(px, "mixed", seed=1, img0=0)
     enc.launch()
     res = enc.results()
-    for knob in ("0", "1"):
+    encq = sq.EncodePlan(px, qoi_compat=1)
+    encq.launch()
+    resq = encq.results()
+    assert (resq["status"] == 0).all()
+    for knob, src, lens in (("0", enc.out, res["len"]), ("1", enc.out, res["len"]), ("1", encq.out, resq["len"]), ("0", encq.out, resq["len"])):
         os.environ["SQOA_HIP_MULTIPASS"] = knob
         try:
-            dec = sq.DecodePlan(enc.out, res["len"], w, h, 4)
+            dec = sq.DecodePlan(src, lens, w, h, 4)
         finally:
             del os.environ["SQOA_HIP_MULTIPASS"]
         with torch.cuda.stream(side):
@@ -424,6 +429,7 @@ def test_plans_replay_from_a_hip_graph(sq, orc):
             assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, px), knob
         dec.close()
     enc.close()
+    encq.close()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
