@@ -105,7 +105,11 @@ int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, siz
  * SQOA_HIP_ENCODE or SQOA_HIP_DECODE.
  * A decode plan chooses per stream between one workgroup per stream (a full batch) and three chip-wide passes (few large
  * streams: one workgroup is one compute unit's speed); SQOA_HIP_MULTIPASS=0 / =1 in the environment when the plan is
- * created or updated forces the one or the other for every stream (tests, measurements; the decoded bytes are the same). */
+ * created or updated forces the one or the other for every stream (tests, measurements; the decoded bytes are the same).
+ * QOI-compat streams among those few large ones are decoded chip-wide by guess and check; creating or
+ * updating such a plan reads one byte of each of these streams where it lies (is any of them QOI-compat framed?) to spare
+ * the others three idle launches -- a hint only: streams that arrive later, or other streams of the same sizes written into
+ * the same buffers, are decoded correctly whatever it said. */
 /* The choice a decode plan makes, as a pure host function (no device needed): order[0 .. *n_multipass) = the streams that take
  * the three passes, largest first; order[*n_multipass .. n) = the dispatch order of the streams that get a workgroup each
  * (largest first, every second run of `cus` reversed so that the compute units' loads even out).  `src_sizes[i]` = stream
