@@ -529,7 +529,7 @@ extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sq
                                                   const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
                                                   hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, hipStream_t stream);
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, hipStream_t stream);
 
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
@@ -539,7 +539,13 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n <= 0) return hipSuccess;
     const int n_multi = dp ? dp->n_images : 0;
     hipError_t e = hipSuccess;
-    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, stream);
+    // (the scan kernels between the passes: only where the speculative pass reads what they leave, or where the rows are too many
+    // for every workgroup to compose them by itself)
+#ifndef SQOA_DP_FUSE_ROWS
+#define SQOA_DP_FUSE_ROWS 1024   /* (a lone 1 Mpixel stream, 670 rows: 0.0355 -> 0.032 ms; 2594 rows, one 3840 x 2160 stream: equal; 64 x 1 Mpixel, 5184 rows: 0.517 -> 0.531 ms) */
+#endif
+    const int scans = n_multi && ((!wave_only && dp->any_qoi) || dp->n_wgs > SQOA_DP_FUSE_ROWS);
+    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, scans, stream);
     if (e != hipSuccess) return e;
     // the QOI-compat streams among them: speculative chip-wide pass + check (sqoa_decode_qoi.hip); what fails the check stays SLOWPATH
     if (n_multi && !wave_only && dp->any_qoi) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results,
                                                              const dp_image* __restrict__ dp_images, const dp_wg* __restrict__ dp_wgs,
-                                                             dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags, uint32_t dp_per) {
+                                                             dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags, uint32_t dp_per,
+                                                             uint32_t dp_fused) {
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
@@ -261,9 +262,63 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     dp_chunk* row = MODE ? dp_tab + tab_off + chunk_first / dp_per : nullptr;
     __shared__ uint32_t s_wg[3][MODE ? DP_CHUNKS_PER_WG_MAX : 1];   // passes 1 and 2: per chunk of the workgroup, what goes into its row
     uint32_t seed_st = ST_N, seed_pos = 0, seed_px = kPxInit;   // ST_N: no preceding op, an ALPHA byte would be a run (seqoia.h:773-775)
+    // What enters this workgroup's first chunk.  Either the two scan kernels between the passes have left it in the row (dp_fused
+    // = 0), or -- few rows, no QOI-compat stream: the launches of those kernels, 5 us each, are a quarter of a lone 1 Mpixel
+    // stream's time -- every workgroup composes the rows in front of its own by itself: pass 2 the transition functions pass 1
+    // left (and keeps the state for pass 3), pass 3 the pixel counts and transforms pass 2 left.  (No workgroup waits for
+    // another: the rows were written by the launch before.)
+    if (MODE >= 2 && dp_fused && chunk_first) {
+        __shared__ uint32_t s_red[3][W];
+        const dp_chunk* tab = dp_tab + tab_off;
+        const uint32_t myrow = chunk_first / dp_per, t = threadIdx.x, per = (myrow + W * 64 - 1) / (W * 64);
+        const uint32_t r0 = t * per < myrow ? t * per : myrow, r1 = r0 + per < myrow ? r0 + per : myrow;
+        if constexpr (MODE == 2) {
+            Fn F{ID_LO, ID_HI};
+            for (uint32_t r = r0; r < r1; ++r) F = compose(Fn{tab[r].g_lo, tab[r].g_hi}, F);
+            const Fn Fi = wave_compose_scan(F);
+            if (lane == 63) { s_red[0][w] = Fi.lo; s_red[1][w] = Fi.hi; }
+            __syncthreads();
+            Fn P{ID_LO, ID_HI};
+            for (int k = 0; k < W; ++k) P = compose(Fn{s_red[0][k], s_red[1][k]}, P);
+            seed_st = bcast_first(apply(P, bcast_first((uint32_t)src[14]) != 0x31u ? (uint32_t)ST_A : (uint32_t)ST_N));
+            if (threadIdx.x == 0) row->st_in = seed_st;
+        } else {
+            const uint32_t hw_ = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+            const uint32_t hh_ = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+            const uint32_t Ncap = hw_ * hh_;
+            uint32_t cnt = 0;
+            Xf T{0u, 0u};
+            for (uint32_t r = r0; r < r1; ++r) {
+                const uint32_t x = cnt + tab[r].ctot;   // (both <= N < 2^31)
+                cnt = x > Ncap ? Ncap : x;
+                T = xf_then(T, Xf{tab[r].tv, tab[r].tabs});
+            }
+            uint32_t v = cnt;
+            v = dp_sat_step<DPP_ROW_SHR + 1, 0xf>(v, Ncap);
+            v = dp_sat_step<DPP_ROW_SHR + 2, 0xf>(v, Ncap);
+            v = dp_sat_step<DPP_ROW_SHR + 4, 0xf>(v, Ncap);
+            v = dp_sat_step<DPP_ROW_SHR + 8, 0xf>(v, Ncap);
+            v = dp_sat_step<DPP_ROW_BCAST15, 0xa>(v, Ncap);
+            v = dp_sat_step<DPP_ROW_BCAST31, 0xc>(v, Ncap);
+            const Xf Ti = wave_xf_scan(T);
+            if (lane == 63) { s_red[0][w] = v; s_red[1][w] = Ti.v; s_red[2][w] = Ti.abs; }
+            __syncthreads();
+            uint32_t pos = 0;
+            Xf P{0u, 0u};
+            for (int k = 0; k < W; ++k) {
+                const uint32_t x = pos + s_red[0][k];
+                pos = x > Ncap ? Ncap : x;
+                P = xf_then(P, Xf{s_red[1][k], s_red[2][k]});
+            }
+            seed_st = bcast_first(row->st_in);
+            seed_pos = bcast_first(pos);
+            seed_px = bcast_first(xf_apply(P, kPxInit));
+        }
+    } else {
     if (MODE >= 2 && chunk_first) seed_st = bcast_first(row->st_in);
     else if (MODE >= 2 && bcast_first((uint32_t)src[14]) != 0x31u) seed_st = ST_A;   // (QOI-compat: the states are A, D1..D4, X)
     if (MODE == 3 && chunk_first) { seed_pos = bcast_first(row->pos_in); seed_px = bcast_first(row->px_in); }
+    }
 
     if (MODE >= 2 && threadIdx.x == 0) s_path = dp_flags[img];   // what pass 1 (or pass 2: SQOA_OP_REF) decided
     if ((MODE == 0 || (MODE == 1 && chunk_first == 0)) && threadIdx.x == 0) {
@@ -770,15 +825,15 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 #define SQOA_DEC_W_SMALL 4
 #endif
     constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL;
-    if (small) hipLaunchKernelGGL((sqoa::decode_wave_kernel<WS, 0>), dim3(n), dim3(WS * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u);
-    else hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u);
+    if (small) hipLaunchKernelGGL((sqoa::decode_wave_kernel<WS, 0>), dim3(n), dim3(WS * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
+    else hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
     return hipGetLastError();
 }
 
 // Few large streams: three passes over all their chunks with the whole chip (see decode_wave_kernel), two one-wave-per-image scans
 // in between.  `d_images` / `d_wgs` / `d_tab` / `d_flags`: the tables the plan built (sqoa_runtime.hip).
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, hipStream_t stream) {
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, hipStream_t stream) {
     if (n_images <= 0 || n_wgs <= 0) return hipSuccess;
     if (per < sqoa::DP_CHUNKS_PER_WG_MIN || per > sqoa::DP_CHUNKS_PER_WG_MAX || per % 8u) return hipErrorInvalidValue;   // (8 waves take the chunks round-robin)
     using namespace sqoa;
@@ -788,11 +843,13 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
     dp_chunk* tab = (dp_chunk*)d_tab;
     uint32_t* fl = (uint32_t*)d_flags;
     // (no initialisation of the flags: pass 1's first workgroup of every image writes its flag before anything reads it)
-    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
-    hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
-    hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, d_jobs, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per);
+    // `scans` = 0: no scan kernels, the workgroups of passes 2 and 3 compose the rows in front of them by themselves (see the kernel)
+    const uint32_t fused = scans ? 0u : 1u;
+    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, 0u);
+    if (scans) hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
+    if (scans) hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, d_jobs, im, tab, fl);
+    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
     return hipGetLastError();
 }
 
