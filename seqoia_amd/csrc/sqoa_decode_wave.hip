@@ -858,18 +858,18 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // still 8 us of a lone stream's 0.10 ms).  Only a hint: a stream the plan does not launch them for stays SLOWPATH and is decoded
 // by the one-workgroup kernel behind.
 namespace sqoa {
-__global__ void dp_classify_kernel(const sqoa_hip_job* __restrict__ jobs, const dp_image* __restrict__ images, int n, uint32_t* __restrict__ word) {
+__global__ void dp_classify_kernel(const sqoa_hip_job* __restrict__ jobs, const int* __restrict__ ids, int n, uint32_t* __restrict__ word) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
-    const sqoa_hip_job job = jobs[images[i].jid];
+    const sqoa_hip_job job = jobs[ids[i]];
     if (job.src_size > (uint32_t)kHeader && ((gcptr8)job.src)[kHeader] != 0x31u) atomicOr(word, 1u);
 }
 }  // namespace sqoa
-extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const void* d_images, int n_images, void* d_word, hipStream_t stream) {
+extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const int* d_ids, int n_images, void* d_word, hipStream_t stream) {
     if (n_images <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_word, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sqoa::dp_classify_kernel, dim3((n_images + 255) / 256), dim3(256), 0, stream, d_jobs, (const sqoa::dp_image*)d_images, n_images, (uint32_t*)d_word);
+    hipLaunchKernelGGL(sqoa::dp_classify_kernel, dim3((n_images + 255) / 256), dim3(256), 0, stream, d_jobs, d_ids, n_images, (uint32_t*)d_word);
     return hipGetLastError();
 }
 
@@ -882,9 +882,9 @@ extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size) {
     const uint32_t area = src_size > 22u ? src_size - 22u : 0u;   // (the QOI-compat chunk area: one byte longer than the SQOA one -- no start byte)
     return area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
 }
-extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes) {
+extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, unsigned wgs, size_t* row_bytes) {
     if (row_bytes) *row_bytes = sizeof(sqoa::dp_chunk);
-    unsigned long long per = (total_chunks / 4096ull + 7ull) & ~7ull;   // about 4096 workgroups: four rounds on the chip
+    unsigned long long per = (total_chunks / (wgs ? wgs : 4096u) + 7ull) & ~7ull;   // about `wgs` workgroups a pass (the plan says how many: sqoa_runtime.hip)
     if (per < sqoa::DP_CHUNKS_PER_WG_MIN) per = sqoa::DP_CHUNKS_PER_WG_MIN;
     if (per > sqoa::DP_CHUNKS_PER_WG_MAX) per = sqoa::DP_CHUNKS_PER_WG_MAX;
     return (uint32_t)per;

@@ -23,9 +23,9 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
-extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, size_t* row_bytes);
+extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, unsigned wgs, size_t* row_bytes);
 extern "C" size_t sqoa_dq_state_bytes(void);
-extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const void* d_images, int n_images, void* d_word, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const int* d_ids, int n, void* d_word, hipStream_t stream);
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
 // empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
@@ -347,6 +347,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     std::vector<dp_image_row> dp_images;
     std::vector<dp_wg_row> dp_wgs;
     size_t dp_rows = 0, dp_row_bytes = 32;
+    int n_multi_dec = 0;
     typedef sqoa::st_image st_image_row;
     typedef sqoa::st_strip st_strip_row;
     std::vector<st_image_row> st_images;
@@ -421,19 +422,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         std::vector<int> sorted(ids_a.size());
         for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
         ids_a.swap(sorted);
-        unsigned long long total_chunks = 0;
-        for (int k = 0; k < n_multi; ++k) total_chunks += sqoa_dp_chunks(jobs[ids_a[k]].src_size);
-        const uint32_t per = sqoa_dp_per_wg(total_chunks, &dp_row_bytes);
-        p->dp.per = per;
-        for (int k = 0; k < n_multi; ++k) {
-            const int i = ids_a[k];
-            const uint32_t nc = sqoa_dp_chunks(jobs[i].src_size), nw = (nc + per - 1) / per;
-            if (dp_wgs.size() + nw > 0x7fffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
-            const uint32_t img = (uint32_t)dp_images.size();
-            dp_images.push_back({i, (uint32_t)dp_rows, nc, nw});
-            for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});
-            dp_rows += nw;
-        }
+        n_multi_dec = n_multi;   // (their tables: below, once the job table is on the device)
     }
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
@@ -445,6 +434,38 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         (e = hipMemcpy(p->d_init, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
         (!ids_a.empty() && (e = hipMemcpy(p->d_ids, ids_a.data(), sizeof(int) * ids_a.size(), hipMemcpyHostToDevice)) != hipSuccess))
         return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
+    p->dp.any_qoi = 0;
+    if (n_multi_dec > 0) {
+        // Which framing do the multi-pass streams use?  One byte of each, read where it lies (the result table is free until a
+        // launch initialises it).  A hint: it picks the shape of the tables and spares plans without QOI-compat streams the
+        // speculative pass's three launches; a stream it misses stays SLOWPATH and goes to the one-workgroup kernel behind.
+        if (!p->wave_only) {   // (SQOA_HIP_JOB_WAVEONLY: the caller has parsed the headers -- SQOA colour streams)
+            uint32_t any = 1;
+            p->dp.any_qoi = 1;
+            if (sqoa_launch_dp_classify(p->d_jobs, p->d_ids, n_multi_dec, p->d_results, p->stream) == hipSuccess &&
+                hipMemcpyAsync(&any, p->d_results, sizeof any, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
+                hipStreamSynchronize(p->stream) == hipSuccess)
+                p->dp.any_qoi = any != 0;
+            else (void)hipGetLastError();
+        }
+        // About 4096 workgroups a pass (four rounds on the chip) -- but ONE SQOA stream alone: about 1024, one round (one 3840 x 2160
+        // stream 0.103 -> 0.091 ms: every workgroup of a pass pays a prologue and the ramp of its chains; the same number of chunks
+        // as 8 x 1 Mpixel the same way: 0.103 -> 0.106 ms, hence one stream only).  Not where the speculative pass will read the
+        // rows: its warm-up is one row, thrown away (0.26 -> 0.49 ms for that stream in QOI-compat).
+        unsigned long long total_chunks = 0;
+        for (int k = 0; k < n_multi_dec; ++k) total_chunks += sqoa_dp_chunks(jobs[ids_a[k]].src_size);
+        const uint32_t per = sqoa_dp_per_wg(total_chunks, !p->dp.any_qoi && n_multi_dec == 1 ? 1024u : 4096u, &dp_row_bytes);
+        p->dp.per = per;
+        for (int k = 0; k < n_multi_dec; ++k) {
+            const int i = ids_a[k];
+            const uint32_t nc = sqoa_dp_chunks(jobs[i].src_size), nw = (nc + per - 1) / per;
+            if (dp_wgs.size() + nw > 0x7fffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
+            const uint32_t img = (uint32_t)dp_images.size();
+            dp_images.push_back({i, (uint32_t)dp_rows, nc, nw});
+            for (uint32_t c0 = 0; c0 < nc; c0 += per) dp_wgs.push_back({img, c0});
+            dp_rows += nw;
+        }
+    }
     p->dp.n_images = (int)dp_images.size();
     p->dp.n_wgs = (int)dp_wgs.size();
     auto grow = [&](void** d, size_t* cap, size_t rows, size_t row_bytes) -> hipError_t {
@@ -508,16 +529,6 @@ strips_done:
             (e = hipMemcpy(p->dp.d_wgs, dp_wgs.data(), sizeof(dp_wg_row) * dp_wgs.size(), hipMemcpyHostToDevice)) != hipSuccess) {
             p->dp.n_images = p->dp.n_wgs = 0;
             return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: tables of the multi-pass decode, upload", e);
-        }
-        // which framing do these streams use?  (one byte of each, read where they lie; the flag words are free until pass 1 writes them)
-        uint32_t any = 1;
-        p->dp.any_qoi = 1;
-        if (!p->wave_only) {
-            if (sqoa_launch_dp_classify(p->d_jobs, p->dp.d_images, p->dp.n_images, p->dp.d_flags, p->stream) == hipSuccess &&
-                hipMemcpyAsync(&any, p->dp.d_flags, sizeof any, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
-                hipStreamSynchronize(p->stream) == hipSuccess)
-                p->dp.any_qoi = any != 0;
-            else (void)hipGetLastError();
         }
     }
     return 0;
