@@ -549,11 +549,12 @@ def run_rank(args):
             graph = None
 
     # The device has been idle while the CPU baseline and the setup ran, and the first ~50 ms of work after an idle period run at
-    # lower clocks (tools/time_warm.py): untimed steps for at least 0.15 s, then the W warm-up steps the caller asked for.
+    # lower clocks (tools/time_warm.py): untimed steps for at least 1 s, then the W warm-up steps the caller asked for.
     # A cold box can take longer (profiles/r03_d_bench.json: 28 spin-up steps at 5.4 ms, then a timed region at 5.27 ms while the
     # kernels measured right after it ran at their usual 1.54 + 3.46 ms): go on in groups of 8 until a group is no faster than the
-    # one before it (within 1.5 %), 1.5 s at most.
-    spin_up, t_spin, prev_group = 0, time.perf_counter(), None
+    # one before it (within 1.5 %), for at least 1 s (profiles/r03_f_bench.json: the same again after 0.17 s of spin-up -- whatever
+    # it is that a cold box ramps, it ramps slowly) and 3 s at most.
+    spin_up, t_spin, prev_group, spin_ms = 0, time.perf_counter(), None, []
     while True:
         t_g = time.perf_counter()
         for _ in range(8):
@@ -561,8 +562,9 @@ def run_rank(args):
         torch.cuda.synchronize()
         spin_up += 8
         group = time.perf_counter() - t_g
+        spin_ms.append(round(group / 8 * 1e3, 4))
         gone = time.perf_counter() - t_spin
-        if gone > 1.5 or (gone >= 0.15 and prev_group is not None and group > 0.985 * prev_group):
+        if gone > 3.0 or (gone >= 1.0 and prev_group is not None and group > 0.985 * prev_group):
             break
         prev_group = group
     for _ in range(args.warmup):
@@ -627,6 +629,7 @@ def run_rank(args):
             "encoded_bytes_check": int(sum(all_lens)),  # from the gathered per-image lengths: equals encoded_bytes_total
             "rate": round(total_enc / total_read, 4),
             "launch": "hip graph replay" if graph is not None else "direct",
+            "spin_up_ms_per_step": [spin_ms[0], min(spin_ms), spin_ms[-1]],  # first group of 8, fastest, last
             "spin_up_steps": spin_up,  # untimed, in front of the W warm-up steps: the clocks ramp up after the idle setup phase
             "encode_mpps_rank0": round(wl.pixels / enc_ms / 1e3, 1),
             "decode_mpps_rank0": round(wl.pixels / dec_ms / 1e3, 1),
