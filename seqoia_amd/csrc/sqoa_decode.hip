@@ -521,7 +521,7 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
 
 }  // namespace sqoa
 
-extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape,
                                               sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
@@ -534,9 +534,11 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
 // streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel.
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int wave_only, const sqoa_dp_tables* dp,
+// `shape`: bit 0 = many short streams, bit 1 = every stream is decoded to four channels (sqoa_launch_decode_wave)
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+    const int small = shape & 1;
     const int n_multi = dp ? dp->n_images : 0;
     hipError_t e = hipSuccess;
     // (the scan kernels between the passes: only where the speculative pass reads what they leave, or where the rows are too many
@@ -551,7 +553,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n_multi && !wave_only && dp->any_qoi) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,
                                                                dp->d_qstate, dp->per, stream);
     if (e != hipSuccess) return e;
-    e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, small, d_results, stream);
+    e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, shape, d_results, stream);
     if (e != hipSuccess) return e;
     if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
 #if !defined(SQOA_QDEC) || SQOA_QDEC

@@ -5,8 +5,8 @@
 // Streams with SQOA_OP_REF, mono streams, QOI-compat streams and 1/2-channel outputs are handed to
 // decode_fallback_kernel (sqoa_decode.hip) by marking the job SQOA_HIP_ST_SLOWPATH.
 //
-// Dataflow per image (one workgroup, W waves; chunk c of 512 stream bytes belongs to wave c mod W, and
-// inside a chunk every lane owns DEC_LB = 8 consecutive stream bytes):
+// Dataflow per image (one workgroup, W waves; chunk c of 512 [768] stream bytes belongs to wave c mod W, and
+// inside a chunk every lane owns LB = 8 [12] consecutive stream bytes):
 //   1. parse: every byte has a transition function over the 7 parser states
 //      {A: op boundary after an op, N: op boundary where an ALPHA suffix is not allowed,
 //       D1..D4: inside an op, X: past the chunk area}; functions are 8 bytes (table in LDS), composition is
@@ -34,12 +34,11 @@
 namespace sqoa {
 
 #ifndef SQOA_DEC_LB
-#define SQOA_DEC_LB 8  /* 12 / 16 amortise the per-chunk scans but spill: 5.5 ms (12, per-op records packed) vs 3.87 ms */
+#define SQOA_DEC_LB 8  /* the chunk geometry of the three passes and their tables; the chained kernel also runs at 12 (SQOA_DEC_LB0, below) */
 #endif
-constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane
-constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step)
-constexpr int DEC_LDS_DW = DEC_CHUNK / 4 + 8;  // staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded
-constexpr int DEC_NLD = (DEC_LDS_DW + 63) / 64;  // dword loads per lane per chunk
+constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane (passes)
+constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step; passes)
+// (staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded: DEC_LDS_DW, DEC_NLD dword loads per lane, in the kernel)
 [[maybe_unused]] constexpr uint32_t DEC_SPIN_MAX = 1u << 22;
 
 // Wait for `slot` to carry `tag`; 0 = it does (val set), 1 = the image was handed over (the slot's owner left DEC_ABORT_TAG in
@@ -68,6 +67,15 @@ SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t
 
 SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
     if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// for (i = I; i < N; ++i) if (!f(i)) break; with i a compile-time constant: the per-op register arrays of the walk are indexed by it,
+// and a loop the compiler declines to unroll fully (it did at 12 ops per lane) sends them to scratch memory
+template <int I, int N, class F>
+SQOA_DEV void static_for(F&& f) {
+    if constexpr (I < N) {
+        if (f(std::integral_constant<int, I>{})) static_for<I + 1, N>(f);
+    }
 }
 
 template <int CTRL, int ROWMASK>
@@ -221,13 +229,27 @@ __global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_pixels(const sqoa_hip
 //           pixel position and the pixel it starts from;
 //   pass 3: parse + walk + scans again, and the stores.
 // Twice the instructions of MODE 0, spread over every CU.
-template <int W, int MODE>
+template <int W, int MODE, int LB = SQOA_DEC_LB>
 __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results,
                                                              const dp_image* __restrict__ dp_images, const dp_wg* __restrict__ dp_wgs,
                                                              dp_chunk* __restrict__ dp_tab, uint32_t* __restrict__ dp_flags, uint32_t dp_per,
                                                              uint32_t dp_fused) {
+    // (the namespace-scope constants of the same names are the passes' chunk geometry, which the plan's tables are laid out for;
+    // the one-workgroup-per-stream kernel, MODE 0, may be built with more stream bytes per lane: SQOA_DEC_LB0)
+    constexpr int DEC_LB = LB, DEC_CHUNK = LB * 64, DEC_LDS_DW = DEC_CHUNK / 4 + 8, DEC_NLD = (DEC_LDS_DW + 63) / 64;
+    // A lane keeps the records of at most DEC_R = 8 ops in registers, and no more than eight walk iterations can START in twelve
+    // bytes of any stream: an iteration takes one byte only when its op is a one-byte RUN without an ALPHA suffix whose successor is
+    // not a RUN it could take along (a RUN behind an op or behind another RUN is taken in the same iteration unless it carries a
+    // suffix of its own) -- so the next iteration is a LUMA / RGB / RGBA op or a RUN + suffix, two bytes or more, and 1, 2, 1, 2, ...
+    // puts the ninth start at byte 12.  (Sixteen bytes per lane would need nine slots for LUMA-dense streams.)  The test behind the
+    // walk is a net, not a path.
+    constexpr int DEC_R = LB < 8 ? LB : 8;
+    constexpr int CL_BITS = 13;                         // pixels in front of an op inside its lane: at most DEC_R - 1 ops of at most 1024 pixels
+    constexpr uint32_t CL_MASK = (1u << CL_BITS) - 1u;
+    static_assert(MODE == 0 || LB == sqoa::DEC_LB, "the passes run at the chunk size the plan lays the tables out for");
+    static_assert(LB % 4 == 0 && (DEC_R - 1) * 1024 <= (int)CL_MASK, "bytes per lane");
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask}; entry 256 = "no op" (lanes out of ops)
@@ -473,12 +495,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         __builtin_memcpy(qd, lb, DEC_LB);   // one ds_read_b64 at a byte address that is 3 mod 4 (the chunk area starts behind 15 header bytes): stalls the LDS pipe
 #else
         {   // three aligned dwords and two v_alignbyte_b32 (as the walk's windows)
-            static_assert(DEC_LB == 8, "parse read");
             const uint32_t off = (gs & 3u) + DEC_LB * lane;
             const uint32_t* pw = lds + (off >> 2);
-            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
-            qd[0] = __builtin_amdgcn_alignbyte(d1, d0, off & 3u);
-            qd[1] = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
+            uint32_t dw[DEC_LB / 4 + 1];
+#pragma unroll
+            for (int k = 0; k <= DEC_LB / 4; ++k) dw[k] = pw[k];
+#pragma unroll
+            for (int k = 0; k < DEC_LB / 4; ++k) qd[k] = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], off & 3u);
         }
 #endif
         Fn F{ID_LO, ID_HI};
@@ -561,11 +584,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         // op belongs to that op (whoever owns the op has read it), so it is skipped too
         uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u);
         bool sfx_ok = lst != ST_N;  // may the byte at `pos` be an ALPHA suffix of the op before it?
-        uint32_t val[DEC_LB];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
-        uint32_t meta[DEC_LB];  // pixels before the op inside my lane (13) | cnt (10) << 13
-        uint32_t amask[DEC_LB]; // byte mask of the channels of val[] that are absolute
+        uint32_t val[DEC_R];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
+        uint32_t meta[DEC_R];  // pixels before the op inside my lane (CL_BITS) | cnt (11) << CL_BITS
+        uint32_t amask[DEC_R]; // byte mask of the channels of val[] that are absolute
         Xf T{0u, 0u};
-        uint32_t cl = 0, iters = DEC_LB, longest = 0;
+        uint32_t cl = 0, iters = DEC_R, longest = 0;
         uint32_t info_or = 0;  // OR of the ops' table words: bit 20 = a lane met SQOA_OP_REF
         // LDS byte address of my first stream byte; the op tables sit at fixed LDS addresses
         const uint32_t lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u) + DEC_LB * lane;
@@ -578,8 +601,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
             hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
         };
-#pragma unroll
-        for (int i = 0; i < DEC_LB; ++i) {
+        static_for<0, DEC_R>([&](auto i_tag) -> bool {
+            constexpr int i = decltype(i_tag)::value;
             // op byte, <= 4 data bytes, possible ALPHA suffix
             if (i == 0) {  // an ALPHA byte at my first op boundary belongs to the op in front of it: step over it
                 uint32_t f0, f1;
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             }
             if (__ballot(pos < nlive) == 0ull) {  // val / meta / amask beyond `iters` stay unwritten and unread
                 iters = i;
-                break;
+                return false;
             }
             // The op decode of seqoia.h:740-783 as table look-ups and mask arithmetic; no compare / select pairs.
             const uint32_t m_act = sra31(pos - nlive);                     // ~0 while I still have an op (pos < nlive <= 8)
@@ -607,11 +630,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const uint32_t adv = len + (se & 1u);
             // A RUN right behind an op repeats exactly the pixel this op produces (pixel pairs, short repeats, split runs):
             // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
-            // (a run behind a run also repeats the same pixel; the 10-bit count field is the only limit)
+            // (a run behind a run also repeats the same pixel -- 0xfd 0xfd, 1024 pixels, included: flat areas are rows of them)
             const uint32_t w2 = w1 >> has8;
             const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
             const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + 4u + ((w2 >> 9) & 0x7f8u));          // ~0 unless an ALPHA byte follows
-            const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1024u);
+            const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1025u);
             const uint32_t extra_m = extra & m_fuse;
             cnt += extra_m;
             // the pixel transform of the op: absolute channels from the stream, the others as deltas
@@ -620,15 +643,17 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
             T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm} HLARG);
             val[i] = T.v;
-            meta[i] = cl | cnt << 13;
+            meta[i] = cl | cnt << CL_BITS;
             amask[i] = T.abs;
             cl += cnt;
             longest = longest > cnt ? longest : cnt;
             pos += adv + ((extra_m + 1023u) >> 10);
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
-        }
+            return true;
+        });
         iters = bcast_first(iters);  // wave-uniform by construction; said so, the slot tests below are scalar compares instead of lane masks
-        const bool ref_lane = (info_or >> 20) & 1u;  // SQOA_OP_REF (what follows it in a lane is discarded with the image)
+        // SQOA_OP_REF (what follows it in a lane is discarded with the image); more ops in a lane's bytes than it has record registers for
+        const bool ref_lane = ((info_or >> 20) & 1u) || (DEC_LB > DEC_R && iters == (uint32_t)DEC_R && pos < nlive);
         if (__ballot(ref_lane) != 0ull) {  // serial path for the whole image
             if (lane == 0) {
                 atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
@@ -675,19 +700,20 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
             if (plain) {  // the common chunk: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
 #if defined(SQOA_DEC_C_STORES) || defined(SQOA_DBG_DEC_NOSTORE)
-#pragma unroll
-                for (int i = 0; i < DEC_LB; ++i) {
-                    if ((uint32_t)i >= iters) break;
+                static_for<0, DEC_R>([&](auto i_tag) -> bool {
+                    constexpr int i = decltype(i_tag)::value;
+                    if ((uint32_t)i >= iters) return false;
                     const uint32_t m = meta[i], am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
-                    gptr32 o = (gptr32)out + lane_p + (m & 0x1fffu);
+                    gptr32 o = (gptr32)out + lane_p + (m & CL_MASK);
 #ifdef SQOA_DBG_DEC_NOSTORE  // timing experiments only
                     asm volatile("" :: "v"(o), "v"(v), "v"(m));
 #else
-                    if (m >> 13) o[0] = v;
-                    if (m >> 14) o[1] = v;  // cnt == 2: a literal op and the one-pixel run behind it
+                    if (m >> CL_BITS) o[0] = v;
+                    if (m >> (CL_BITS + 1)) o[1] = v;  // cnt == 2: a literal op and the one-pixel run behind it
 #endif
-                }
+                    return true;
+                });
 #else
                 // Hand-written: the compiler's version of `if (cnt >= 1) o[0] = v; if (cnt == 2) o[1] = v;` is, per slot, two
                 // s_and_saveexec / s_cbranch_execz / s_or exec triples around stores with 64-bit address arithmetic (7 scalar
@@ -696,31 +722,32 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 // lane of the wave is alive here (wave-uniform control flow, full workgroups): EXEC is all ones on entry.
                 const uint32_t lane_off = lane_p << 2;
                 const unsigned long long obase = job.dst;
-#pragma unroll
-                for (int i = 0; i < DEC_LB; ++i) {
-                    if ((uint32_t)i >= iters) break;
+                static_for<0, DEC_R>([&](auto i_tag) -> bool {
+                    constexpr int i = decltype(i_tag)::value;
+                    if ((uint32_t)i >= iters) return false;
                     const uint32_t m = meta[i], am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i] HLARG);
-                    const uint32_t off = lane_off + ((m & 0x1fffu) << 2);
+                    const uint32_t off = lane_off + ((m & CL_MASK) << 2);
                     asm volatile(
-                        "v_cmpx_lt_u32_e32 vcc, 0x1fff, %[m]\n\t"          // cnt >= 1
+                        "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // cnt >= 1
                         "global_store_dword %[off], %[v], %[base]\n\t"
-                        "v_cmpx_lt_u32_e32 vcc, 0x3fff, %[m]\n\t"          // cnt == 2: a literal op and the one-pixel run behind it
+                        "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // cnt == 2: a literal op and the one-pixel run behind it
                         "global_store_dword %[off], %[v], %[base] offset:4\n\t"
                         "s_mov_b64 exec, -1"
-                        :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase) : "memory", "vcc");
-                }
+                        :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+                    return true;
+                });
                 asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
 #endif
             } else {
             auto store_ops = [&](auto oc_tag) {
                 constexpr int OC = decltype(oc_tag)::value;
-#pragma unroll
-                for (int i = 0; i < DEC_LB; ++i) {
-                    if ((uint32_t)i >= iters) break;
+                static_for<0, DEC_R>([&](auto i_tag) -> bool {
+                    constexpr int i = decltype(i_tag)::value;
+                    if ((uint32_t)i >= iters) return false;
                     const uint32_t m = meta[i];
-                    const uint32_t cnt = m >> 13;
-                    const uint32_t P = lane_p + (m & 0x1fffu);
+                    const uint32_t cnt = m >> CL_BITS;
+                    const uint32_t P = lane_p + (m & CL_MASK);
                     const uint32_t am = amask[i];
                     const uint32_t v = add8(lane_px & ~am, val[i]);
                     if (cnt >= 1u && cnt <= 2u && P < N) put_pixel<OC>(out, P, v);
@@ -734,7 +761,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                         if (rp + rc > N) rc = N - rp;
                         fill_pixels<OC>(out, rp, rc, rv, lane);
                     }
-                }
+                    return true;
+                });
             };
             if (oc == 4 && dw_out) store_ops(std::integral_constant<int, 4>{});
             else if (oc == 4) store_ops(std::integral_constant<int, 40>{});
@@ -813,9 +841,16 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
 }  // namespace sqoa
 
-// `small`: the plan's streams are short and many (sqoa_runtime.hip): four waves per stream instead of eight, twice as many
+// `shape` bit 0: the plan's streams are short and many (sqoa_runtime.hip): four waves per stream instead of eight, twice as many
 // streams at once (16 384 x 128 x 128: 0.83 -> 0.73 ms, 8192 x 256 x 256: 1.83 -> 1.73 ms; 512 x 512 and up: no difference).
-extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small,
+// `shape` bit 1: TWELVE stream bytes per lane instead of eight (768-byte chunks).  What a chunk costs whatever its size -- the two
+// chain hops, the three wave scans, the scalar control around them: 134 of 480 VALU and most of the scalar instructions -- is
+// spread over 1.5 x the bytes; the walk keeps its eight record slots per lane (DEC_R).  Headline batch 3.41 -> 3.09 ms, icons
+// 4096 x 512 x 512 1.94 -> 1.77 ms, C5 rank shard 12.7 -> 12.0 ms.  The plan asks for it when every stream is decoded to FOUR
+// channels: to three (byte stores, three per pixel) the stores are what the waves queue for, and twelve bytes per lane spread a
+// store instruction's 64 pixels over 1.5 x the cache lines -- photo 1024 x 1 Mpixel RGB 2.90 -> 3.16 ms (11 % FEWER instructions,
+// 24 % more issue-stall cycles: profiles/r04_a_photo_rgb_*).
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape,
                                               sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
 #ifndef SQOA_DEC_W
@@ -824,9 +859,17 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 #ifndef SQOA_DEC_W_SMALL
 #define SQOA_DEC_W_SMALL 4
 #endif
-    constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL;
-    if (small) hipLaunchKernelGGL((sqoa::decode_wave_kernel<WS, 0>), dim3(n), dim3(WS * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
-    else hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u);
+#ifndef SQOA_DEC_LB0   // stream bytes per lane of the one-workgroup-per-stream kernel when the plan asks for the wide shape (the passes keep SQOA_DEC_LB: the plan's tables)
+#define SQOA_DEC_LB0 12
+#endif
+    constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL, LB0 = SQOA_DEC_LB0, LB = SQOA_DEC_LB;
+    const bool small = shape & 1, wide = (shape & 2) && LB0 != LB;
+#define SQOA_DEC_LAUNCH(W_, LB_) hipLaunchKernelGGL((sqoa::decode_wave_kernel<W_, 0, LB_>), dim3(n), dim3(W_ * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u)
+    if (small && wide) SQOA_DEC_LAUNCH(WS, LB0);
+    else if (small) SQOA_DEC_LAUNCH(WS, LB);
+    else if (wide) SQOA_DEC_LAUNCH(W, LB0);
+    else SQOA_DEC_LAUNCH(W, LB);
+#undef SQOA_DEC_LAUNCH
     return hipGetLastError();
 }
 

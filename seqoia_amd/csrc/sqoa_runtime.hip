@@ -19,7 +19,7 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int wave_only, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
@@ -111,6 +111,7 @@ struct sqoa_hip_plan {
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
+    int wide = 0;                       // decode: every stream goes to four output channels -- the wave decoder takes twelve stream bytes per lane (sqoa_launch_decode_wave)
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
@@ -411,7 +412,13 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         for (size_t k = 0; k < ids_a.size(); ++k) { sizes[k] = jobs[ids_a[k]].src_size; bytes += sizes[k]; }
         p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
         p->wave_only = 1;
-        for (int i : ids_a) if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
+        p->wide = 1;
+        for (int i : ids_a) {
+            if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
+            if (jobs[i].desc.channels != 4) p->wide = 0;
+        }
+        // (SQOA_HIP_DEC_WIDE=0 / =1 in the environment: never / always -- tests and measurements; the results are the same)
+        if (const char* kw = getenv("SQOA_HIP_DEC_WIDE")) p->wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : p->wide;
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
@@ -603,7 +610,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small | p->wide << 1, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }

@@ -27,12 +27,15 @@ def orc():
     return po
 
 
-@pytest.fixture(params=["0", "1"], ids=["chained", "threepass"])
+@pytest.fixture(params=[("0", "0"), ("0", "1"), ("1", "0")], ids=["chained", "chained-wide", "threepass"])
 def route(request, monkeypatch):
-    """Both routes of the SQOA wave decoder (the plan reads SQOA_HIP_MULTIPASS when it is filled): one workgroup per stream
-    with the chunks chained through LDS, and the three chip-wide passes the plan picks by itself for few large streams."""
-    monkeypatch.setenv("SQOA_HIP_MULTIPASS", request.param)
-    return request.param
+    """Every route of the SQOA wave decoder (the plan reads SQOA_HIP_MULTIPASS / SQOA_HIP_DEC_WIDE when it is filled): one
+    workgroup per stream with the chunks chained through LDS -- eight stream bytes per lane, or twelve (what the plan picks by
+    itself when every stream goes to four channels; forced here for every channel count) -- and the three chip-wide passes the plan
+    picks by itself for few large streams."""
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", request.param[0])
+    monkeypatch.setenv("SQOA_HIP_DEC_WIDE", request.param[1])
+    return request.param[0]
 
 
 def test_legacy_decode_kats(sq, kat_decode):
@@ -136,7 +139,8 @@ def test_batch_decode_mutants_match_oracle(sq, orc, route):
 
 
 def test_wave_decoder_chunk_boundaries(sq, orc, route):
-    """Crafted multi-chunk SQOA streams (the wave decoder cuts the stream every 512 bytes, 8 bytes per lane):
+    """Crafted multi-chunk SQOA streams (the wave decoder cuts the stream every 512 bytes, 8 bytes per lane -- or every 768, 12 per
+    lane: the `route` fixture):
     every alignment of 1/2/3/4/5/6-byte ops against lane and chunk boundaries, ALPHA suffix as first byte of a
     lane / chunk, op bytes that look like op starts, REF op deep in the stream (hand-over to the serial kernel
     while other waves wait), stream exhausted in the middle of an op."""
@@ -176,9 +180,11 @@ def test_wave_decoder_chunk_boundaries(sq, orc, route):
 
     END = bytes(7) + b"\x01"
     streams = []
+    # (["run", "run_a"]: a RUN does not take the RUN behind it into its walk iteration when that one carries an ALPHA suffix -- one
+    # byte, then two: eight ops start in twelve bytes, as many as a lane has record registers for)
     mixes = [["luma"], ["luma", "luma_a"], ["rgb", "luma"], ["rgba", "luma_a", "run"], ["rgba_a", "rgb_a", "run_a", "alpha_alpha"],
-             ["run", "bigrun", "luma"], ["luma", "luma_a", "rgb", "rgb_a", "rgba", "rgba_a", "run", "run_a", "bigrun", "alpha_alpha"]]
-    for shift in range(9):  # leading run bytes move every later op by one byte
+             ["run", "bigrun", "luma"], ["run", "run_a"], ["bigrun"], ["luma", "luma_a", "rgb", "rgb_a", "rgba", "rgba_a", "run", "run_a", "bigrun", "alpha_alpha"]]
+    for shift in range(13):  # leading run bytes move every later op by one byte
         for mix in mixes:
             streams.append(hdr(96, 64) + b"\xc0" * shift + body(700, mix) + END)
     full = mixes[-1]

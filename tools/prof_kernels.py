@@ -14,6 +14,7 @@ ap.add_argument("--what", default="both")
 ap.add_argument("--qoi", type=int, default=0)
 ap.add_argument("--cls", default="mixed")
 ap.add_argument("--channels", type=int, default=4)
+ap.add_argument("--out-channels", type=int, default=4)
 a = ap.parse_args()
 px = torch.empty((a.images, a.size, a.size, a.channels), dtype=torch.uint8, device="cuda")
 sq.synth(px, a.cls, 1, 0)
@@ -23,8 +24,8 @@ assert (res["status"] == 0).all()
 if a.what in ("encode", "both"):
     print("encode ms/launch", enc.time(a.iters) / a.iters, "Mpx/s", a.images * a.size * a.size / (enc.time(a.iters) / a.iters) / 1e3)
 if a.what in ("decode", "both"):
-    dec = sq.DecodePlan(enc.out, res["len"], a.size, a.size, 4)
+    dec = sq.DecodePlan(enc.out, res["len"], a.size, a.size, a.out_channels)
     dec.launch(); dres = dec.results()
     assert (dres["status"] == 0).all()
-    assert torch.equal(dec.out[..., :a.channels], px)
+    assert torch.equal(dec.out[..., :min(a.channels, a.out_channels)], px[..., :min(a.channels, a.out_channels)])
     print("decode ms/launch", dec.time(a.iters) / a.iters, "Mpx/s", a.images * a.size * a.size / (dec.time(a.iters) / a.iters) / 1e3)
