@@ -79,6 +79,13 @@ typedef struct sqoa_hip_plan sqoa_hip_plan;
 int sqoa_hip_device_count(void);
 const char *sqoa_hip_last_error(void);
 
+/* The allocator of the four legacy entry points (seqoia.h): every buffer sqoa_encode / sqoa_decode / sqoa_read return, and the
+ * file buffer inside sqoa_read, comes from `malloc_fn` and is released -- by the CALLER for what is returned -- with `free_fn`.
+ * The reference selects these at compile time (#define SQOA_MALLOC / SQOA_FREE, seqoia.h:390-396), which cannot reach a prebuilt
+ * library: a caller that built the reference with an arena allocator calls this once, before its first codec call (the two
+ * pointers are process-wide and not synchronised against calls in flight).  NULL = back to malloc / free, the default. */
+void sqoa_hip_set_allocator(void *(*malloc_fn)(size_t), void (*free_fn)(void *));
+
 /* Worst-case stream size for one image: w*h*(ch+1)+14+8 (reference
  * seqoia.h:487-489) plus the start byte the reference forgets (seqoia.h:513),
  * rounded up to 256 so consecutive slots stay aligned. 0 if desc is invalid. */
@@ -109,7 +116,13 @@ int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, siz
  * QOI-compat streams among those few large ones are decoded chip-wide by guess and check; creating or
  * updating such a plan reads one byte of each of these streams where it lies (is any of them QOI-compat framed?) to spare
  * the others three idle launches -- a hint only: streams that arrive later, or other streams of the same sizes written into
- * the same buffers, are decoded correctly whatever it said. */
+ * the same buffers, are decoded correctly whatever it said.
+ * REQUIREMENT that follows: the `src` of a decode job that takes the chip-wide route (a job of a plan with few, large streams)
+ * must be mapped, readable device memory when sqoa_hip_plan_create / sqoa_hip_plan_update is called (its CONTENT may still be
+ * on its way from a producer on another stream: the read is one byte, on the plan's own stream, and not ordered against anybody;
+ * what it sees only steers the hint).  Jobs flagged SQOA_HIP_JOB_WAVEONLY are never read at fill time.
+ * A decode plan whose every job asks for 4 output channels runs the wave decoder with twelve stream bytes per lane instead of
+ * eight; SQOA_HIP_DEC_WIDE=0 / =1 in the environment forces the one or the other (tests, measurements). */
 /* The choice a decode plan makes, as a pure host function (no device needed): order[0 .. *n_multipass) = the streams that take
  * the three passes, largest first; order[*n_multipass .. n) = the dispatch order of the streams that get a workgroup each
  * (largest first, every second run of `cus` reversed so that the compute units' loads even out).  `src_sizes[i]` = stream

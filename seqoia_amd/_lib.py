@@ -58,6 +58,7 @@ SYMBOLS = {
     "sqoa_decode": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(Desc), C.c_int]),
     "sqoa_write": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(Desc)]),
     "sqoa_read": (C.c_void_p, [C.c_char_p, C.POINTER(Desc), C.c_int]),
+    "sqoa_hip_set_allocator": (None, [C.c_void_p, C.c_void_p]),
     "sqoa_hip_device_count": (C.c_int, []),
     "sqoa_hip_last_error": (C.c_char_p, []),
     "sqoa_hip_encode_bound": (C.c_size_t, [C.POINTER(Desc)]),

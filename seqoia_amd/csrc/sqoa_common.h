@@ -27,6 +27,7 @@ struct sqoa_dp_tables {
     void* d_flags;                  // one word per image, written by pass 1: 1 wave path, 2 left to the other kernels, 3 QOI-compat colour stream: speculative pass
     void* d_qstate;                 // two decoder states (pixel + colour index, 512 bytes each) per workgroup row: the speculative pass of QOI-compat streams
     int any_qoi;                    // a HINT, taken when the plan was filled: some of these streams are in QOI-compat framing (0: the speculative pass and its check are not launched)
+    int cus;                        // compute units of the plan's device
 };
 
 // Tables of the strip encode of few large images (sqoa_strips.hip); built by the plan (sqoa_runtime.hip).
@@ -50,7 +51,17 @@ struct dp_image { int jid; uint32_t tab_off, nchunks, nwgs; };   // one multi-pa
 struct dp_wg { uint32_t img, chunk0; };                           // one workgroup of a pass: image and first chunk
 struct st_image { int jid; uint32_t first, nstrips, npx; unsigned long long ws; };   // strip rows [first, first + nstrips), workspace
 struct st_strip { uint32_t img, k; };
-static_assert(sizeof(dp_image) == 16 && sizeof(dp_wg) == 8 && sizeof(st_image) == 24 && sizeof(st_strip) == 8, "table rows are packed");
+// What the LDS chain of the wave decoder carries, per workgroup of a pass, in HBM: the composite of its chunks' transition functions,
+// pixel counts and transforms (written by passes 1 and 2), and what enters its first chunk (written by the two scans; read by the
+// speculative pass of sqoa_decode_qoi.hip as well).
+struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };
+static_assert(sizeof(dp_image) == 16 && sizeof(dp_wg) == 8 && sizeof(st_image) == 24 && sizeof(st_strip) == 8 && sizeof(dp_chunk) == 32, "table rows are packed");
+// Stream bytes per chunk of the PASSES (decode_wave_kernel MODE 1..3, the speculative pass of decode_qoi_kernel and the plan's
+// tables all count chunks of this size; the one-workgroup-per-stream kernels are free to cut their streams differently).
+#ifndef SQOA_DEC_LB
+#define SQOA_DEC_LB 8
+#endif
+constexpr int DP_CHUNK_BYTES = 64 * SQOA_DEC_LB;
 
 // Device addresses arrive as integers in the job table; tell the compiler they are GLOBAL
 // (address space 1) so it emits global_load/global_store, not flat_*.

@@ -527,7 +527,7 @@ extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const i
 
 extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                   const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
-                                                  hipStream_t stream);
+                                                  int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                 const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, hipStream_t stream);
 
@@ -551,7 +551,7 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (e != hipSuccess) return e;
     // the QOI-compat streams among them: speculative chip-wide pass + check (sqoa_decode_qoi.hip); what fails the check stays SLOWPATH
     if (n_multi && !wave_only && dp->any_qoi) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,
-                                                               dp->d_qstate, dp->per, stream);
+                                                               dp->d_qstate, dp->per, dp->cus, stream);
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, shape, d_results, stream);
     if (e != hipSuccess) return e;

@@ -97,7 +97,8 @@ SQOA_DEV uint32_t select_mask(uint32_t if_clear, uint32_t if_set, unsigned long 
 // What the speculative pass (SPEC, below) leaves per workgroup for the check that follows it: the resolver's state -- running pixel and
 // the 64 index entries -- where the workgroup's own chunks begin (behind its warm-up) and where they end.
 struct dq_state { uint32_t px, tab[64], pad[63]; };   // 512 bytes
-struct dp_chunk_row { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };   // = sqoa::dp_chunk (sqoa_decode_wave.hip)
+typedef dp_chunk dp_chunk_row;   // (sqoa_common.h: the rows passes 1 and 2 of decode_wave_kernel and the two scans leave)
+static_assert(QK_CHUNK == DP_CHUNK_BYTES, "the speculative pass indexes the passes' tables with its own chunk numbers");
 
 // SPEC = false: one workgroup per stream, from its first byte (the batch shape).
 // SPEC = true: the chip-wide route for FEW LARGE QOI-compat streams.  A stream's decoder state (pixel, index[64]) cannot be summarised
@@ -670,17 +671,12 @@ __global__ __launch_bounds__(1024) void dq_verify_kernel(const sqoa_hip_job* __r
 // The speculative chip-wide pass over the QOI-compat streams among a plan's few large streams, and the check behind it.
 extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                   const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
-                                                  hipStream_t stream) {
+                                                  int cus, hipStream_t stream) {
     if (n_images <= 0 || n_wgs <= 0 || !d_qstate) return hipSuccess;
     using namespace sqoa;
     // A workgroup decodes `span` rows of the tables behind one row of warm-up: as few rows as fill the chip's workgroup slots once
     // (the warm-up is work thrown away: at one row each, half of everything).
-    static int cus = 0;   // (one kind of device per process)
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
+    if (cus <= 0) cus = 256;   // (the plan's device: sqoa_dp_tables.cus)
     const unsigned slots = (unsigned)cus * 4u;
     const unsigned span = ((unsigned)n_wgs + slots - 1) / slots;
     // A guess that fails (content that lives on INDEX ops: entries written once, read for ever) has cost this pass on top of the

@@ -33,9 +33,7 @@
 
 namespace sqoa {
 
-#ifndef SQOA_DEC_LB
-#define SQOA_DEC_LB 8  /* the chunk geometry of the three passes and their tables; the chained kernel also runs at 12 (SQOA_DEC_LB0, below) */
-#endif
+// (SQOA_DEC_LB, sqoa_common.h: the chunk geometry of the three passes and their tables; the chained kernel also runs at 12, SQOA_DEC_LB0 below)
 constexpr int DEC_LB = SQOA_DEC_LB;            // stream bytes owned by one lane (passes)
 constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wave step; passes)
 // (staged dwords per wave: chunk + 8 look-ahead + 3 misalignment, rounded: DEC_LDS_DW, DEC_NLD dword loads per lane, in the kernel)
@@ -119,7 +117,8 @@ SQOA_DEV Xf wave_xf_scan(Xf T) {
 // (dp_image, dp_wg: sqoa_common.h)
 // What the LDS chain carries, per workgroup (DP_CHUNKS_PER_WG chunks), in HBM: the composite of its chunks' transition functions,
 // pixel counts and transforms (written by passes 1 and 2), and what enters its first chunk (written by the two scans).
-struct dp_chunk { uint32_t g_lo, g_hi, st_in, ctot, tv, tabs, pos_in, px_in; };
+// (dp_chunk: sqoa_common.h)
+static_assert(DEC_CHUNK == DP_CHUNK_BYTES, "the passes' chunk size");
 #ifndef SQOA_DP_PER_MIN
 #define SQOA_DP_PER_MIN 8   /* one chunk per wave: a lone 1 Mpixel stream 0.040 -> 0.036 ms; from 8 streams on no difference */
 #endif
@@ -245,8 +244,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     // suffix of its own) -- so the next iteration is a LUMA / RGB / RGBA op or a RUN + suffix, two bytes or more, and 1, 2, 1, 2, ...
     // puts the ninth start at byte 12.  (Sixteen bytes per lane would need nine slots for LUMA-dense streams.)  The test behind the
     // walk is a net, not a path.
-    constexpr int DEC_R = LB < 8 ? LB : 8;
-    constexpr int CL_BITS = 13;                         // pixels in front of an op inside its lane: at most DEC_R - 1 ops of at most 1024 pixels
+#ifndef SQOA_DEC_R16
+#define SQOA_DEC_R16 10
+#endif
+    constexpr int DEC_R = LB < 8 ? LB : LB <= 12 ? 8 : SQOA_DEC_R16;
+    constexpr int CL_BITS = DEC_R <= 8 ? 13 : 14;                         // pixels in front of an op inside its lane: at most DEC_R - 1 ops of at most 1024 pixels
     constexpr uint32_t CL_MASK = (1u << CL_BITS) - 1u;
     static_assert(MODE == 0 || LB == sqoa::DEC_LB, "the passes run at the chunk size the plan lays the tables out for");
     static_assert(LB % 4 == 0 && (DEC_R - 1) * 1024 <= (int)CL_MASK, "bytes per lane");
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
         const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
         const uint32_t hc = src[12], hs = src[13], q = src[14] != 0x31;
+        res->len = 0; res->status = SQOA_HIP_ST_OK;   // the row as every launch must find it: nobody else has touched it yet (sqoa_runtime.hip, plan_enqueue)
         res->desc.width = hw; res->desc.height = hh; res->desc.channels = (uint8_t)hc;
         res->desc.colorspace = (uint8_t)hs; res->desc.qoi_compat = (uint8_t)q;
         const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+    const unsigned long long tr_start = wall_clock64();   // workgroup start / end (100 MHz) and placement: tools/trace_decode.py
 #define DPHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
 #elif defined(SQOA_ASM_MARK)  // phase markers as comments in the assembly (tools/asm_cost.py by region)
 #define DPHASE(k) asm volatile("; SQOA_PHASE " #k)
@@ -718,10 +722,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 // Hand-written: the compiler's version of `if (cnt >= 1) o[0] = v; if (cnt == 2) o[1] = v;` is, per slot, two
                 // s_and_saveexec / s_cbranch_execz / s_or exec triples around stores with 64-bit address arithmetic (7 scalar
                 // instructions + 3 branches + 10 VALU); here the two predicates narrow EXEC directly (v_cmpx), the stores take the
-                // image base from an SGPR pair and a 32-bit byte offset (an image is < 1.6 GB), and EXEC is put back once.  Every
-                // lane of the wave is alive here (wave-uniform control flow, full workgroups): EXEC is all ones on entry.
+                // image base from an SGPR pair and a 32-bit byte offset (an image is < 1.6 GB), and EXEC is put back once -- to what
+                // it was on entry, read here once per chunk (all ones today: wave-uniform control flow, full workgroups; the block
+                // does not rely on it).
                 const uint32_t lane_off = lane_p << 2;
                 const unsigned long long obase = job.dst;
+                const unsigned long long exec_in = __builtin_amdgcn_read_exec();
                 static_for<0, DEC_R>([&](auto i_tag) -> bool {
                     constexpr int i = decltype(i_tag)::value;
                     if ((uint32_t)i >= iters) return false;
@@ -733,8 +739,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                         "global_store_dword %[off], %[v], %[base]\n\t"
                         "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // cnt == 2: a literal op and the one-pixel run behind it
                         "global_store_dword %[off], %[v], %[base] offset:4\n\t"
-                        "s_mov_b64 exec, -1"
-                        :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+                        "s_mov_b64 exec, %[ex]"
+                        :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [ex] "s"(exec_in), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
                     return true;
                 });
                 asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
@@ -835,7 +841,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     }
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
 #ifdef SQOA_TRACE
-    if (threadIdx.x == 0) { unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull); for (int k = 0; k < 8; ++k) tr[k] = ph[k]; }
+    __syncthreads();   // (every wave that has not left early: the workgroup's end)
+    if (threadIdx.x == 0) {
+        unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull);
+        for (int k = 0; k < 8; ++k) tr[k] = ph[k];
+        tr[8] = tr_start; tr[9] = wall_clock64();
+        tr[10] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32;
+    }
 #endif
 }
 

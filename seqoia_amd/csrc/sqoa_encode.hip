@@ -569,6 +569,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const int jid = job_ids[blockIdx.x];
     if (jid < 0) return;   // a skipped row of a strip table (sqoa_strips.hip)
     const sqoa_hip_job job = jobs[jid];
+    // the result row as every launch must find it (no copy in front of the kernels: sqoa_runtime.hip, plan_enqueue); the barrier
+    // below orders it in front of whatever a wave writes there later
+    if (threadIdx.x == 0) { results[jid].len = 0; results[jid].status = SQOA_HIP_ST_OK; }
 
     const uint32_t N = job.desc.width * job.desc.height;
     const int dch = job.desc.channels;
@@ -1375,15 +1378,16 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 // ---- launch -----------------------------------------------------------------------------
 
 extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, hipStream_t stream);
+                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream);
+// `cus`: compute units of the device the plan lives on (the plan asks the device it was created for, not the calling thread's current one)
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                         sqoa_hip_result* d_results, hipStream_t stream) {
-    return sqoa_launch_encode_tab(d_jobs, d_ids, n, qoi, d_results, nullptr, stream);
+                                         sqoa_hip_result* d_results, int cus, hipStream_t stream) {
+    return sqoa_launch_encode_tab(d_jobs, d_ids, n, qoi, d_results, nullptr, cus, stream);
 }
 
 // `d_qtab_in` (QOI-compat strip jobs only, else null): the colour index entering job i, 64 dwords at [64 * i]
 extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, hipStream_t stream) {
+                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     // 8 waves per image, four images per CU: the kernel is VALU-issue bound (tools/ubench/valu_table.hip)
 #ifndef SQOA_ENC_W
@@ -1396,12 +1400,7 @@ extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const i
     // 4096 icons of 512 x 512 RGB 3.10 -> 2.93 ms; two waves per image: 4.6 / 3.9 ms).  Fewer images than 2 per CU, and
     // strips (a workgroup per CU-sized piece of one image): eight waves (256 images 1.37 against 1.98 ms).
     if (qoi) {
-        static int cus = 0;   // (one kind of device per process)
-        if (!cus) {
-            int dev = 0, k = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&k, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || k <= 0) k = 256;
-            cus = k;
-        }
+        if (cus <= 0) cus = 256;
 #ifndef SQOA_ENC_W_QOI_MANY
 #define SQOA_ENC_W_QOI_MANY 4
 #endif

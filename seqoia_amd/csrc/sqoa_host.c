@@ -23,6 +23,17 @@
 
 #define SQOA_PIXELS_MAX 400000000u /* reference seqoia.h:432 */
 
+/* The reference takes its allocator at COMPILE time (#define SQOA_MALLOC / SQOA_FREE in front of the implementation,
+ * seqoia.h:390-396): every buffer it returns, and the file buffer of sqoa_read, comes from it.  A prebuilt library cannot see
+ * the caller's macros; this is the run-time counterpart (sqoa_hip.h).  Default: malloc / free, as the reference's default. */
+static void *(*g_malloc)(size_t) = malloc;
+static void (*g_free)(void *) = free;
+
+void sqoa_hip_set_allocator(void *(*malloc_fn)(size_t), void (*free_fn)(void *)) {
+    g_malloc = malloc_fn ? malloc_fn : malloc;
+    g_free = free_fn ? free_fn : free;
+}
+
 /* Per-thread device context: the reference is re-entrant (only a const table
  * at seqoia.h:439), so concurrent callers must not share mutable state. */
 typedef struct {
@@ -124,9 +135,9 @@ void *sqoa_encode(const void *data, const sqoa_desc *desc, int *out_len) {
     job.desc = *desc;
     sqoa_hip_result res;
     if (run_job(c, SQOA_HIP_ENCODE, &job, &res) || res.status != SQOA_HIP_ST_OK || res.len <= 0) return NULL;
-    unsigned char *out = malloc((size_t)res.len); /* caller free()s: sqoabench.c:537, seqoia.h:834 */
+    unsigned char *out = g_malloc((size_t)res.len); /* SQOA_MALLOC, seqoia.h:492; the caller frees: sqoabench.c:537, seqoia.h:834 */
     if (!out) return NULL;
-    if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, (size_t)res.len)) { free(out); return NULL; }
+    if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, (size_t)res.len)) { g_free(out); return NULL; }
     *out_len = res.len;
     return out;
 }
@@ -181,9 +192,9 @@ void *sqoa_decode(const void *data, int size, sqoa_desc *desc, int channels) {
     }
     if (res.status != SQOA_HIP_ST_OK || (size_t)res.len != out_bytes) return NULL;
 
-    void *out = malloc(out_bytes); /* caller free()s: sqoabench.c:454, :493 */
+    void *out = g_malloc(out_bytes); /* SQOA_MALLOC, seqoia.h:710; the caller frees: sqoabench.c:454, :493 */
     if (!out) return NULL;
-    if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, out_bytes)) { free(out); return NULL; }
+    if (sqoa_hip_memcpy_d2h(c->device, out, c->d_out, out_bytes)) { g_free(out); return NULL; }
     return out;
 }
 
@@ -199,7 +210,7 @@ int sqoa_write(const char *filename, const void *data, const sqoa_desc *desc) { 
     fflush(f);
     const int err = ferror(f);
     fclose(f);
-    free(enc);
+    g_free(enc); /* SQOA_FREE, seqoia.h:834 */
     return err ? 0 : size;
 }
 
@@ -209,12 +220,12 @@ void *sqoa_read(const char *filename, sqoa_desc *desc, int channels) { /* seqoia
     fseek(f, 0, SEEK_END);
     const long size = ftell(f);
     if (size <= 0 || size > 0x7fffffffL || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return NULL; }
-    void *data = malloc((size_t)size);
+    void *data = g_malloc((size_t)size); /* SQOA_MALLOC, seqoia.h:849 */
     if (!data) { fclose(f); return NULL; }
     const size_t got = fread(data, 1, (size_t)size, f);
     fclose(f);
     void *px = got == (size_t)size ? sqoa_decode(data, (int)size, desc, channels) : NULL;
-    free(data);
+    g_free(data); /* SQOA_FREE, seqoia.h:864 */
     return px;
 }
 

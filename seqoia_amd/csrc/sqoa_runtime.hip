@@ -16,7 +16,7 @@
 #include "sqoa_common.h"
 
 extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                         sqoa_hip_result* d_results, hipStream_t stream);
+                                         sqoa_hip_result* d_results, int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
@@ -102,18 +102,21 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 struct sqoa_hip_plan {
     int device = 0;
+    int cus = 256;                      // compute units of `device` (asked when the plan is filled): the launchers' shape choices
     int kind = 0;
     int n = 0, cap = 0;
     sqoa_hip_job* d_jobs = nullptr;
     sqoa_hip_result* d_results = nullptr;
-    sqoa_hip_result* d_init = nullptr;  // results as they must read before a launch (BADARG rows pre-filled)
+    sqoa_hip_result* d_init = nullptr;  // staging of the result rows as a fill leaves them (BADARG / OVERFLOW rows pre-filled): copied to d_results ONCE per fill --
+                                        // a launch touches only the rows of valid jobs, and the first kernel that takes a job resets its row itself
+    uint32_t* d_word = nullptr;         // one scratch word (the framing hint of the multi-pass streams, plan_fill)
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int wide = 0;                       // decode: every stream goes to four output channels -- the wave decoder takes twelve stream bytes per lane (sqoa_launch_decode_wave)
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
-    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1};   // decode: the few large streams that take the three-pass route
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};   // encode: the few large images cut into strips
     int n_cut_sqoa = 0, n_cut_qoi = 0;   // how many at the front of the SQOA / QOI-compat id list they are
@@ -343,6 +346,8 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     p->dp.n_images = p->dp.n_wgs = 0;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
+    p->cus = cus;
+    p->dp.cus = cus;
     typedef sqoa::dp_image dp_image_row;   // (sqoa_common.h: the kernels read the very same structs)
     typedef sqoa::dp_wg dp_wg_row;
     std::vector<dp_image_row> dp_images;
@@ -439,18 +444,21 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     hipError_t e;
     if ((e = hipMemcpy(p->d_jobs, jobs, sizeof(sqoa_hip_job) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(p->d_init, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToDevice)) != hipSuccess ||
         (!ids_a.empty() && (e = hipMemcpy(p->d_ids, ids_a.data(), sizeof(int) * ids_a.size(), hipMemcpyHostToDevice)) != hipSuccess))
         return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
     p->dp.any_qoi = 0;
     if (n_multi_dec > 0) {
-        // Which framing do the multi-pass streams use?  One byte of each, read where it lies (the result table is free until a
-        // launch initialises it).  A hint: it picks the shape of the tables and spares plans without QOI-compat streams the
-        // speculative pass's three launches; a stream it misses stays SLOWPATH and goes to the one-workgroup kernel behind.
+        // Which framing do the multi-pass streams use?  One byte of each (byte 14), read where it lies: the streams of a plan's few
+        // LARGE jobs must be readable device memory when the plan is created or updated (sqoa_hip.h says so), and what a producer
+        // on another stream has not written yet reads as whatever is there -- which is why this is only a hint.  It picks the shape
+        // of the tables and spares plans without QOI-compat streams the speculative pass's three launches; a stream it misses
+        // stays SLOWPATH and goes to the one-workgroup kernel behind.
         if (!p->wave_only) {   // (SQOA_HIP_JOB_WAVEONLY: the caller has parsed the headers -- SQOA colour streams)
             uint32_t any = 1;
             p->dp.any_qoi = 1;
-            if (sqoa_launch_dp_classify(p->d_jobs, p->d_ids, n_multi_dec, p->d_results, p->stream) == hipSuccess &&
-                hipMemcpyAsync(&any, p->d_results, sizeof any, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
+            if (sqoa_launch_dp_classify(p->d_jobs, p->d_ids, n_multi_dec, p->d_word, p->stream) == hipSuccess &&
+                hipMemcpyAsync(&any, p->d_word, sizeof any, hipMemcpyDeviceToHost, p->stream) == hipSuccess &&
                 hipStreamSynchronize(p->stream) == hipSuccess)
                 p->dp.any_qoi = any != 0;
             else (void)hipGetLastError();
@@ -557,6 +565,7 @@ int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, 
     hipError_t e;
     if ((e = hipMalloc((void**)&p->d_jobs, jb)) != hipSuccess || (e = hipMalloc((void**)&p->d_results, rb)) != hipSuccess ||
         (e = hipMalloc((void**)&p->d_init, rb)) != hipSuccess || (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_word, 256)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&p->ev0)) != hipSuccess ||
         (e = hipEventCreate(&p->ev1)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming)) != hipSuccess) {
         sqoa_hip_plan_destroy(p);
@@ -583,6 +592,7 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->d_jobs) hipFree(p->d_jobs);
     if (p->d_results) hipFree(p->d_results);
     if (p->d_init) hipFree(p->d_init);
+    if (p->d_word) hipFree(p->d_word);
     if (p->d_ids) hipFree(p->d_ids);
     for (void* d : {p->st.d_images, p->st.d_strips, p->st.d_cuts, p->st.d_jobs, p->st.d_ids, p->st.d_results, p->st.d_offsets, p->st.d_ws, p->st.d_qtab, p->st.d_qtin})
         if (d) hipFree(d);
@@ -600,14 +610,16 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
 static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
     if (p->n == 0) return 0;
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);  // the calling thread's current device may be another one
-    HIP_TRY(hipMemcpyAsync(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)p->n, hipMemcpyDeviceToDevice, s), SQOA_HIP_ELAUNCH);
+    // (no copy of the initial result rows in front of the kernels: the rows of refused jobs were written when the plan was filled
+    // and nothing touches them, every other row is reset by the first kernel that takes its job -- encode_kernel, the first
+    // workgroup of strip_pack_kernel, decode_wave_kernel in its one-workgroup shape or as the first workgroup of pass 1)
     if (p->kind == SQOA_HIP_ENCODE) {
         HIP_TRY(sqoa_launch_encode_strips(p->d_jobs, p->d_results, &p->st, s), SQOA_HIP_ELAUNCH);
         // each id list: [images cut into strips (above) | one workgroup each | many small ones, one wave each]
         const int* ida = p->d_ids; const int* idb = p->d_ids + p->n_sqoa;
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, ida + p->n_cut_sqoa, p->n_sqoa - p->n_cut_sqoa - p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, ida + p->n_cut_sqoa, p->n_sqoa - p->n_cut_sqoa - p->n_sqoa_small, 0, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, ida + p->n_sqoa - p->n_sqoa_small, p->n_sqoa_small, 0, p->d_results, s), SQOA_HIP_ELAUNCH);
-        HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
         HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small | p->wide << 1, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);

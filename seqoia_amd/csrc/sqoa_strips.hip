@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void strip_pack_kernel(const sqoa_hip_job* __r
 }  // namespace sqoa
 
 extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi, sqoa_hip_result* d_results,
-                                             const uint32_t* d_qtab_in, hipStream_t stream);
+                                             const uint32_t* d_qtab_in, int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_pack_offsets(const sqoa_hip_result* d_res, int n, unsigned long long* d_offsets, hipStream_t stream);
 
 // The images of the tables: SQOA-native ones first (strip rows [0, n_strips - n_strips_qoi)), QOI-compat ones behind them.
@@ -198,13 +198,13 @@ extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa
     const int ns_q = st->n_strips_qoi, ns_s = st->n_strips - ns_q, ni_q = st->n_images_qoi, ni_s = st->n_images - ni_q;
     hipLaunchKernelGGL(strip_cut_kernel, dim3(st->n_strips), dim3(64), 0, stream, d_jobs, im, ss, (uint32_t*)st->d_cuts);
     hipLaunchKernelGGL(strip_job_kernel, dim3(st->n_images), dim3(64), 0, stream, d_jobs, im, (const uint32_t*)st->d_cuts, sjobs, (int*)st->d_ids, sres);
-    hipError_t e = sqoa_launch_encode_tab(sjobs, sids, ns_s, 0, sres, nullptr, stream);
+    hipError_t e = sqoa_launch_encode_tab(sjobs, sids, ns_s, 0, sres, nullptr, 0, stream);
     if (e != hipSuccess) return e;
     if (ns_q > 0) {
         hipLaunchKernelGGL(strip_qtab_kernel, dim3(ns_q), dim3(256), 0, stream, sjobs, sids, (uint32_t)ns_s, (unsigned long long*)st->d_qtab);
         hipLaunchKernelGGL(strip_qscan_kernel, dim3(ni_q), dim3(64), 0, stream, im, (uint32_t)ni_s, (const unsigned long long*)st->d_qtab, (uint32_t*)st->d_qtin);
         // (the kernel indexes the entering tables by job id = strip row)
-        e = sqoa_launch_encode_tab(sjobs, sids + ns_s, ns_q, 1, sres, (const uint32_t*)st->d_qtin, stream);
+        e = sqoa_launch_encode_tab(sjobs, sids + ns_s, ns_q, 1, sres, (const uint32_t*)st->d_qtin, 0, stream);
         if (e != hipSuccess) return e;
     }
     e = sqoa_launch_pack_offsets(sres, st->n_strips, (unsigned long long*)st->d_offsets, stream);

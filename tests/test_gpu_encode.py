@@ -720,3 +720,93 @@ def test_large_single_image(sq, orc, mode, ch):
     dec.close()
     enc.close()
     assert sq.encode(px, sq.Desc(w, h, ch, 0, mode)) == want
+
+
+def test_legacy_calls_take_their_buffers_from_the_callers_allocator(sq, orc, tmp_path):
+    """sqoa_hip_set_allocator: the run-time counterpart of the reference's compile-time SQOA_MALLOC / SQOA_FREE
+    (seqoia.h:390-396).  Every buffer the four legacy entry points return -- and the file buffer inside sqoa_read, seqoia.h:849 /
+    :864; the stream sqoa_write encodes, seqoia.h:823 / :834 -- comes from the caller's malloc and goes back through the
+    caller's free; the bytes are the reference's."""
+    import ctypes as C
+
+    from seqoia_amd import _lib
+
+    lib = _lib.load()
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.free.restype, libc.free.argtypes = None, [C.c_void_p]
+    live, log = {}, []
+
+    @C.CFUNCTYPE(C.c_void_p, C.c_size_t)
+    def my_malloc(n):
+        p = libc.malloc(n)
+        live[p] = n
+        log.append(("malloc", n))
+        return p
+
+    @C.CFUNCTYPE(None, C.c_void_p)
+    def my_free(p):
+        assert p in live, "freed what it never allocated"
+        log.append(("free", live.pop(p)))
+        libc.free(p)
+
+    w, h, ch = 96, 33, 4
+    px = orc.synth(w, h, ch, "mixed", 5, 0)
+    want = orc.best().encode(px, w, h, ch, 0)
+    lib.sqoa_hip_set_allocator(C.cast(my_malloc, C.c_void_p), C.cast(my_free, C.c_void_p))
+    try:
+        d, n, dd = sq.Desc(w, h, ch, 0, 0), C.c_int(0), sq.Desc()
+        p = lib.sqoa_encode(px.ctypes.data, C.byref(d), C.byref(n))
+        assert p in live and live[p] == n.value == len(want) and C.string_at(p, n.value) == want
+        q = lib.sqoa_decode(p, n.value, C.byref(dd), 0)
+        assert q in live and live[q] == w * h * ch and C.string_at(q, w * h * ch) == px.tobytes()
+        my_free(p)
+        my_free(q)   # (the caller releases what it was handed with the same allocator)
+        assert not live
+        f = str(tmp_path / "a.sqoa").encode()
+        del log[:]
+        assert lib.sqoa_write(f, px.ctypes.data, C.byref(d)) == len(want)
+        assert log == [("malloc", len(want)), ("free", len(want))] and not live and open(f, "rb").read() == want
+        del log[:]
+        r = lib.sqoa_read(f, C.byref(dd), 4)
+        assert r in live and C.string_at(r, w * h * 4) == px.tobytes()
+        assert log == [("malloc", len(want)), ("malloc", w * h * 4), ("free", len(want))]
+        my_free(r)
+    finally:
+        lib.sqoa_hip_set_allocator(None, None)
+    # back on malloc / free
+    p = lib.sqoa_encode(px.ctypes.data, C.byref(d), C.byref(n))
+    assert p and p not in live and C.string_at(p, n.value) == want
+    _lib.c_free(p)
+
+
+def test_plans_run_on_the_last_visible_device(sq, orc):
+    """Multi-GPU hygiene (one process per GPU, the images sharded, no collective): nothing in a plan may assume device 0.
+    Encode + decode plans on device `device_count() - 1` while the calling thread's current device is 0 -- both wire formats,
+    the chip-wide routes included (a lone large image), every result the reference's.  (On a one-GPU box the last device is
+    device 0 and this is one more parity test; on any larger box it is the test of everything that takes a device index.)"""
+    import torch
+
+    o = orc.best()
+    last = torch.cuda.device_count() - 1
+    assert sq.load().sqoa_hip_device_count() == torch.cuda.device_count()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", last)
+    for (n, w, h, ch) in ((6, 160, 120, 4), (1, 1024, 700, 3)):
+        host = np.stack([orc.synth(w, h, ch, "mixed", 9, k).reshape(h, w, ch) for k in range(n)])
+        px = torch.from_numpy(host).to(dev)
+        for mode in (0, 1):
+            enc = sq.EncodePlan(px, qoi_compat=mode)
+            assert enc.device == last
+            enc.launch()
+            res = enc.results()
+            assert (res["status"] == 0).all()
+            for k in range(n):
+                assert bytes(enc.out[k, : int(res["len"][k])].cpu().numpy()) == o.encode(host[k].reshape(-1), w, h, ch, mode), (n, mode, k)
+            dec = sq.DecodePlan(enc.out, res["len"], w, h, 4)
+            dec.launch()
+            dres = dec.results()
+            assert (dres["status"] == 0).all() and dec.out.device == dev
+            assert np.array_equal(dec.out[..., :ch].cpu().numpy(), host)
+            dec.close()
+            enc.close()

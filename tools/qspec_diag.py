@@ -1,5 +1,7 @@
+"""Which classes / images does the speculative QOI-compat decode route hold on?  (A stream it had to hand back shows as a decode time of a
+one-workgroup decode, > 1 ms for 1 Mpixel: a timing heuristic -- tools/qspec_why.py reads the check's own verdict from a -DSQOA_DQ_DEBUG build.)"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, seqoia_amd as sq
 os.environ["SQOA_HIP_MULTIPASS"] = "1"
 for cls, ch in (("mixed", 4), ("photo", 3), ("icon", 3), ("mixed", 3)):

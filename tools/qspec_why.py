@@ -1,3 +1,6 @@
+"""Why the speculative QOI-compat decode route rejects a stream: first failing workgroup and reason code, as left in the result row by
+dq_verify_kernel -- NEEDS a build with -DSQOA_DQ_DEBUG (tools/mkvariant.sh dqdbg "-DSQOA_DQ_DEBUG", SQOA_LIB=variants/dqdbg.so); a plain
+build reports nothing here."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, seqoia_amd as sq
