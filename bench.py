@@ -423,28 +423,34 @@ def legacy_calls(sq, headline, runs=10):
             "protocol": "sqoabench BENCHMARK_FN: 1 warm-up discarded, mean of 10 runs, malloc+free timed, host buffers (H2D + kernels + D2H per call)"}
 
 
-def traffic_from_profile(kernel, images, size):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, only when it was taken from THIS kernel source
-    (the summary records the hash of seqoia_amd/csrc) on the same image shape; scaled to this rank's number of images (the
-    images are independent and equal in size: traffic is per image); otherwise None."""
+def counters_from_profile(kernel, images, size):
+    """What the committed rocprofv3 PMC summary says about a headline kernel -- HBM bytes per launch, instructions retired per 64
+    pixels by kind, LDS bank-conflict cycles per active LDS cycle, the clock the chip held (SQ_BUSY_CYCLES / 32 shader engines /
+    the kernel's average duration in the same round's kernel stats) -- only when it was taken from THIS kernel source (the summary
+    records the hash of seqoia_amd/csrc) on the same image shape; the bytes are scaled to this rank's number of images (the
+    images are independent and equal in size: traffic is per image).  {} otherwise."""
     import hashlib
 
     pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
     if not os.path.exists(pmc) or images <= 0:
-        return None, None
+        return {}
     d = json.load(open(pmc))
     hsh = hashlib.sha256()
     src = os.path.join(ROOT, "seqoia_amd", "csrc")
     for f in sorted(os.listdir(src)):
         hsh.update(open(os.path.join(src, f), "rb").read())
     if d.get("csrc_sha256") != hsh.hexdigest() or d.get("size", 1024) != size:
-        return None, None
+        return {}
     k = d["kernels"].get(kernel)
     if not k:
-        return None, None
+        return {}
     # gfx950: FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md, HBM); KB
     per_launch = (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024
-    return int(per_launch * images / d.get("images", 1024)), "profiles/pmc_hbm_latest.json"
+    out = {"traffic": int(per_launch * images / d.get("images", 1024)), "source": "profiles/pmc_hbm_latest.json"}
+    for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz", "rocprof_avg_ms", "rocprof_min_ms", "kernel"):
+        if f in k:
+            out[f] = k[f]
+    return out
 
 
 # ---- one rank --------------------------------------------------------------------------------------------------------
@@ -638,29 +644,41 @@ def run_rank(args):
     }
     # Both kernels are HBM-bound by their algorithmic bytes; the decoder is the dominant one by time, the
     # encoder is the one the north-star's target (>= 50 % of the HBM-read roofline) is stated on.
-    if c5:
-        enc_traffic = dec_traffic = src = None
-    else:
-        enc_traffic, src = traffic_from_profile("encode", wl.n, s)
-        dec_traffic, _ = traffic_from_profile("decode", wl.n, s)
+    enc_pmc = {} if c5 else counters_from_profile("encode", wl.n, s)
+    dec_pmc = {} if c5 else counters_from_profile("decode", wl.n, s)
+    src = enc_pmc.get("source") or dec_pmc.get("source")
     dominant = "decode" if dec_ms >= enc_ms else "encode"
-    roof_enc = {
-        "kernel": "sqoa::encode_kernel<8,false>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-        "achieved": round(wl.read_bytes / enc_ms / 1e6, 1),  # algorithmic READ bytes (channels B/px) / kernel time
+
+    def pmc_fields(row, pmc):
+        # from the committed PMC summary of this very source (None / absent otherwise): HBM bytes per launch, instructions retired
+        # per 64 pixels by kind, LDS conflict ratio, the clock the chip held under this kernel, the kernel ALONE as rocprofv3 timed it
+        row["traffic"] = pmc.get("traffic")
+        for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz"):
+            if f in pmc:
+                row[f] = pmc[f]
+        if "rocprof_avg_ms" in pmc:
+            row["kernel_ms_rocprof"] = {"avg": pmc["rocprof_avg_ms"], "min": pmc["rocprof_min_ms"]}
+        return row
+
+    # `plan_launch_ms`: HIP events around whole plan launches (the kernel named here plus the plan's stand-by launches behind it:
+    # two for a decode plan, ~10 us in all), k launches back to back on the plan's stream, in a loop of its own behind the timed region
+    roof_enc = pmc_fields({
+        "kernel": enc_pmc.get("kernel", "sqoa::encode_kernel<8, false>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "achieved": round(wl.read_bytes / enc_ms / 1e6, 1),  # algorithmic READ bytes (channels B/px) / plan launch time
         "frac": round(wl.read_bytes / enc_ms / 1e6 / HBM_PEAK_GBS, 4),
         "achieved_read_plus_write": round((wl.read_bytes + wl.enc_bytes) / enc_ms / 1e6, 1),
         # the encoder also writes enc_bytes / read_bytes bytes per byte read: at the measured copy rate of the chip (6.29 TB/s of read +
         # write traffic) the READ rate cannot exceed this fraction of the 8 TB/s peak on this content
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS / (1.0 + wl.enc_bytes / wl.read_bytes), 4),
-        "kernel_ms": round(enc_ms, 4), "traffic": enc_traffic,
-    }
-    roof_dec = {
-        "kernel": "sqoa::decode_wave_kernel<8,0>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "plan_launch_ms": round(enc_ms, 4),
+    }, enc_pmc)
+    roof_dec = pmc_fields({
+        "kernel": dec_pmc.get("kernel", "sqoa::decode_wave_kernel<8, 0, 12>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
         "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
         "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS, 4),   # all of its bytes are streaming traffic
-        "kernel_ms": round(dec_ms, 4), "traffic": dec_traffic,
-    }
+        "plan_launch_ms": round(dec_ms, 4),
+    }, dec_pmc)
     out["roofline"] = dict(roof_dec if dominant == "decode" else roof_enc)
     out["roofline"]["dominant_by_time"] = dominant
     out["roofline"]["share_of_step"] = round(max(enc_ms, dec_ms) / (enc_ms + dec_ms), 3)

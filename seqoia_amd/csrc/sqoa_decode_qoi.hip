@@ -56,7 +56,7 @@ constexpr int QK_LB = 8;                          // stream bytes per lane
 constexpr int QK_CHUNK = 64 * QK_LB;              // stream bytes per chunk
 constexpr int QK_LDS_DW = QK_CHUNK / 4 + 8;       // staged dwords: chunk + look-ahead + misalignment
 constexpr int QK_NLD = (QK_LDS_DW + 63) / 64;
-constexpr uint32_t QK_SPIN_MAX = 1u << 24;
+[[maybe_unused]] constexpr uint32_t QK_SPIN_MAX = 1u << 24;
 
 // One step of the segmented transform scan: `hf` (all ones / zero) marks lanes whose segment head lies at or below them
 // within the distance covered so far; such lanes keep their transform, the others prepend the one arriving from below.
@@ -72,8 +72,15 @@ SQOA_DEV Xf qk_seg_step(Xf T, uint32_t& hf) {
     return R;
 }
 
+// Wait for the 8-byte chain word to carry `tag` (high half); the low half comes back in `val`.  The hand-written poll of
+// sqoa_common.h: the loop as the compiler builds it is 25 scalar instructions and 8 branches on the path where the first look
+// succeeds, four waits per chunk and producer, and the producers retire as many scalar instructions as vector ones -- the one
+// scalar pipe of the compute unit is what bounds them (profiles/r03_f_qoi_pmc_summary.txt: 165 SALU + 60 branches per 64 pixels).
+// (What the tag guards was written to LDS by the posting wave BEFORE its one ds_write_b64 of tag and value -- qk_post -- and LDS
+// executes a wave's instructions in order; the poll waits for its own reads, lgkmcnt(0), before anything behind it is issued.)
 template <int SLEEP = SQOA_QDEC_SLEEP>
 SQOA_DEV bool qk_wait(unsigned long long* slot, uint32_t tag, uint32_t& val, uint32_t& bad) {
+#ifdef SQOA_QDEC_C_POLL   // the loop as the compiler makes it (A/B builds)
     for (uint32_t spin = 0; spin < QK_SPIN_MAX; ++spin) {
         const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (bcast_first((uint32_t)(v >> 32)) == tag) { val = bcast_first((uint32_t)v); return true; }
@@ -81,6 +88,11 @@ SQOA_DEV bool qk_wait(unsigned long long* slot, uint32_t tag, uint32_t& val, uin
     }
     bad = 1;
     return false;
+#else
+    const uint32_t t = chain_poll<SLEEP>(slot, tag, 0xffffffffu, val);   // (no tag is ever 2^32 - 1: chunk numbers + 1)
+    if (t != tag) { bad = 1; return false; }
+    return true;
+#endif
 }
 // (release: everything the wave wrote to LDS before -- index updates included -- is done when the tag becomes visible)
 SQOA_DEV void qk_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
@@ -385,8 +397,27 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t v = live ? recv[gb + lane] : 0u;
             const uint32_t pinc = wave_incl_scan(cnt);
             const uint32_t Pp = P0 + pinc - cnt;
+            const uint32_t gtot = bcast_lane(pinc, 63);
+#ifdef SQOA_QDEC_ASM_STORES   // A/B builds: decode_wave_kernel's hand-written store path carried over -- headline batch 9.45 -> 9.68 ms, icons 2.20 -> 2.23 ms: off
+            if (dw_out && P0 + gtot <= N) {
+                // the common group -- dword pixels, nothing clipped: the two predicates narrow EXEC directly (v_cmpx), the stores take
+                // the image base from an SGPR pair and a 32-bit byte offset, EXEC is put back once
+                const unsigned long long obase = job.dst, exec_in = __builtin_amdgcn_read_exec();
+                const uint32_t off = Pp << 2, c1 = cnt - 1u;
+                asm volatile(
+                    "v_cmpx_gt_u32_e32 vcc, 2, %[c1]\n\t"           // cnt is 1 or 2
+                    "global_store_dword %[off], %[v], %[base]\n\t"
+                    "v_cmpx_eq_u32_e32 vcc, 1, %[c1]\n\t"           // cnt == 2: an op and the one-pixel run behind it
+                    "global_store_dword %[off], %[v], %[base] offset:4\n\t"
+                    "s_mov_b64 exec, %[ex]\n\t"
+                    "s_nop 4"                                          // (a VALU write of EXEC wants 5 wait states in front of a DPP instruction)
+                    :: [c1] "v"(c1), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [ex] "s"(exec_in) : "memory", "vcc");
+            } else
+#endif
+            {
             if (cnt >= 1u && cnt <= 2u && Pp < N) put(Pp, v);
             if (cnt == 2u && Pp + 1u < N) put(Pp + 1u, v);
+            }
             unsigned long long runs = __ballot(cnt > 2u && Pp < N);
             while (runs) {  // seqoia.h:723-725
                 const int l = __builtin_ctzll(runs);
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (rp + rc > N) rc = N - rp;
                 for (uint32_t k = lane; k < rc; k += 64) put(rp + k, rvv);
             }
-            P0 += bcast_lane(pinc, 63);
+            P0 += gtot;
         }
         if (held == nchunks - 1) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             for (uint32_t k = held_out + lane; k < N; k += 64) put(k, pxv);

@@ -261,6 +261,15 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ __attribute__((aligned(16))) u32x4 s_optab[257];
     // byte -> {ALPHA suffix: delta << 24 | 8, else 0 ;  0 for an ALPHA suffix byte, else ~0}
     __shared__ __attribute__((aligned(8))) uint32_t s_sfx[256][2];
+    // A/B builds (SQOA_DEC_TAB4=1): the walk's three one-dword look-ups by a stream byte -- the ALPHA suffix behind the op, "is the
+    // byte behind that a RUN", "is the byte behind the RUN an ALPHA suffix" -- from tables of their own at a 4-byte stride: at the 16-
+    // and 8-byte strides of s_optab and s_sfx a dword read of 32 lanes can only fall on 8 resp. 16 of the 32 LDS banks (bank = dword
+    // address mod 32), and the kernel's SQ_LDS_BANK_CONFLICT is 1.5 x its SQ_ACTIVE_INST_LDS.  Measured: 3.178 vs 3.185 ms on the
+    // headline batch, 1.787 vs 1.782 ms on the icons -- the LDS pipe's conflicts are not what the waves wait for.  Off.
+#ifndef SQOA_DEC_TAB4
+#define SQOA_DEC_TAB4 0
+#endif
+    __shared__ uint32_t s_t4[SQOA_DEC_TAB4 ? 3 : 1][SQOA_DEC_TAB4 ? 256 : 1];   // [0]: s_sfx[.][0], [1]: run pixels << 21, [2]: s_sfx[.][1]
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         s_optab[b0] = e;
         s_sfx[b0][0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 9u) : 0u;  // delta << 24 | 8 (shift) | 1 (length)
         s_sfx[b0][1] = is_sfx ? 0u : 0xffffffffu;
+        if (SQOA_DEC_TAB4) { s_t4[0][b0] = s_sfx[b0][0]; s_t4[SQOA_DEC_TAB4 ? 1 : 0][b0] = is_run ? cnt : 0u; s_t4[SQOA_DEC_TAB4 ? 2 : 0][b0] = is_sfx ? 0u : 0xffffffffu; }
     }
     if (threadIdx.x == 0) { u32x4 z = {4u << 3, 0u, 0u, 0u}; s_optab[256] = z; }
     __syncthreads();
@@ -629,15 +639,25 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op.  w1 = stream >> (8 * len - 4).
             const unsigned long long q = (unsigned long long)hi << 32 | lo;
             const uint32_t w1 = (uint32_t)(q >> ((e.x >> 3) & 63u));
+#if SQOA_DEC_TAB4
+            const uint32_t t4_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_t4[0][0];
+            const uint32_t se = *(lcptr32)(uintptr_t)(t4_addr + ((w1 >> 2) & 0x3fcu & m_act));
+#else
             const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 >> 1) & 0x7f8u & m_act));
+#endif
             const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
             const uint32_t adv = len + (se & 1u);
             // A RUN right behind an op repeats exactly the pixel this op produces (pixel pairs, short repeats, split runs):
             // take it in the same iteration when it is mine (starts inside my bytes) and carries no ALPHA suffix of its own.
             // (a run behind a run also repeats the same pixel -- 0xfd 0xfd, 1024 pixels, included: flat areas are rows of them)
             const uint32_t w2 = w1 >> has8;
+#if SQOA_DEC_TAB4
+            const uint32_t extra = *(lcptr32)(uintptr_t)(t4_addr + 1024u + ((w2 >> 2) & 0x3fcu));        // 0 unless RUN / BIGRUN
+            const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(t4_addr + 2048u + ((w2 >> 10) & 0x3fcu));      // ~0 unless an ALPHA byte follows
+#else
             const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
             const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + 4u + ((w2 >> 9) & 0x7f8u));          // ~0 unless an ALPHA byte follows
+#endif
             const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1025u);
             const uint32_t extra_m = extra & m_fuse;
             cnt += extra_m;

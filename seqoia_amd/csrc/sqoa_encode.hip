@@ -534,7 +534,9 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
 #endif
 // (one wave per image, W = 1: 24 workgroups of 6.7 KB of LDS fit a CU, six waves per SIMD -- asking for eight only earned a
 // "failed to meet occupancy target" from the compiler; the staging buffer, the landing buffer and the run-byte table are 6.6 KB)
+#ifndef SQOA_ENC_WPE_ATTR
 #define SQOA_ENC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(QOI ? SQOA_ENC_WPE_QOI : (W == 1 ? 6 : SQOA_ENC_WPE), QOI ? 6 : (W == 1 ? 6 : SQOA_ENC_WPE))))
+#endif
 template <int W, bool QOI>
 __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                         const int* __restrict__ job_ids,

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""tools/pmc_latest.py SUMMARY.txt TAG -> profiles/pmc_hbm_latest.json: the HBM counters of the headline kernels from a
-tools/pmc_table.py summary, stamped with the hash of seqoia_amd/csrc so that bench.py reports `roofline.traffic` only
-for the kernel source the counters were taken from."""
-import hashlib, json, os, re, sys
+"""tools/pmc_latest.py SUMMARY.txt TAG [KERNEL_STATS.csv] -> profiles/pmc_hbm_latest.json: the counters of the headline kernels from a
+tools/pmc_table.py summary -- HBM bytes (FETCH_SIZE / WRITE_SIZE), instructions retired by kind (SQ_INSTS_*), LDS busy / bank-conflict
+cycles, SQ_BUSY_CYCLES -- and the kernels' average duration from the rocprofv3 kernel stats of the same round, stamped with the hash of
+seqoia_amd/csrc so that bench.py reports `roofline.traffic`, `insts_per_64px` and `clock_ghz` only for the kernel source the counters
+were taken from."""
+import csv, hashlib, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "seqoia_amd", "csrc")
 h = hashlib.sha256()
@@ -17,15 +19,32 @@ for ln in open(sys.argv[1]):
         m = re.match(r"\s+(\S+)\s+([0-9.]+)", ln)
         if m:
             kern[cur][m.group(1)] = float(m.group(2))
-out_images = 1024
-pick = lambda pre: next((v for k, v in kern.items() if k.startswith(pre)), None)
-enc, dec = pick("sqoa::encode_kernel<8, false>"), (pick("sqoa::decode_wave_kernel<8, 0>") or pick("sqoa::decode_wave_kernel"))
-out = {"note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py on the headline batch (1024 x 1024x1024 RGBA), KB per launch; "
-               f"gfx950: FETCH_SIZE counts 1/2 of streamed read bytes (MI355X_MICROARCH.md, HBM) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. "
-               f"Full table: profiles/{sys.argv[2]}_pmc_summary.txt (tools/profile_round.sh {sys.argv[2]})",
-       "csrc_sha256": h.hexdigest(), "images": out_images, "size": 1024, "kernels": {}}
-for name, k in (("encode", enc), ("decode", dec)):
-    if k and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-        out["kernels"][name] = {"FETCH_SIZE_KB": k["FETCH_SIZE"], "WRITE_SIZE_KB": k["WRITE_SIZE"]}
+dur = {}
+if len(sys.argv) > 3 and os.path.exists(sys.argv[3]):
+    for r in csv.DictReader(open(sys.argv[3])):
+        dur[r["Name"].split("(")[0].replace("void ", "")] = {"avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "calls": int(r["Calls"])}
+out_images, size = 1024, 1024
+pick = lambda d, pre: next(((k, v) for k, v in d.items() if k.startswith(pre)), (None, None))
+out = {"note": f"rocprofv3 --pmc passes (one counter group per pass: HBM bytes, SQ_INSTS_*, busy / LDS cycles) of bench.py on the headline batch (1024 x 1024x1024 RGBA), per launch; "
+               f"gfx950: FETCH_SIZE counts 1/2 of streamed read bytes (MI355X_MICROARCH.md, HBM) -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
+               f"clock = SQ_BUSY_CYCLES / 32 shader engines / the kernel's average duration in the kernel stats of the same round. "
+               f"Full table: profiles/{sys.argv[2]}_pmc_summary.txt, profiles/{sys.argv[2]}_kernel_stats.csv (tools/profile_round.sh {sys.argv[2]})",
+       "csrc_sha256": h.hexdigest(), "images": out_images, "size": size, "kernels": {}}
+groups = out_images * size * size / 64.0
+for name, pre in (("encode", "sqoa::encode_kernel<8, false>"), ("decode", "sqoa::decode_wave_kernel<8, 0")):
+    kname, k = pick(kern, pre)
+    if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        continue
+    row = {"kernel": kname, "FETCH_SIZE_KB": k["FETCH_SIZE"], "WRITE_SIZE_KB": k["WRITE_SIZE"]}
+    if all(c in k for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS")):
+        row["insts_per_64px"] = {c[9:].lower(): round(k[c] / groups, 2) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS")}
+    if "SQ_LDS_BANK_CONFLICT" in k and k.get("SQ_ACTIVE_INST_LDS"):
+        row["lds_conflict_cycles_per_active_cycle"] = round(k["SQ_LDS_BANK_CONFLICT"] / k["SQ_ACTIVE_INST_LDS"], 3)
+    _, d = pick(dur, pre)
+    if d:
+        row["rocprof_avg_ms"], row["rocprof_min_ms"], row["rocprof_calls"] = round(d["avg_ns"] / 1e6, 4), round(d["min_ns"] / 1e6, 4), d["calls"]
+        if "SQ_BUSY_CYCLES" in k:
+            row["clock_ghz"] = round(k["SQ_BUSY_CYCLES"] / 32.0 / d["avg_ns"], 3)
+    out["kernels"][name] = row
 json.dump(out, open(os.path.join(root, "profiles", "pmc_hbm_latest.json"), "w"), indent=1)
 print(json.dumps(out["kernels"]))

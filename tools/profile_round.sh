@@ -18,6 +18,13 @@ rocprofv3 --output-format csv --pmc $SQ1 -d $out/pmc_sq_$tag -o run -- python3 b
 rocprofv3 --output-format csv --pmc $SQ2 -d $out/pmc_sq2_$tag -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-secondary > /dev/null 2>&1
 python3 tools/pmc_table.py "$out/pmc_fetch_$tag/**/*counter_collection.csv" "$out/pmc_write_$tag/**/*counter_collection.csv" "$out/pmc_sq_$tag/**/*counter_collection.csv" "$out/pmc_sq2_$tag/**/*counter_collection.csv" > $out/${tag}_pmc_summary.txt
 find $out/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
+# workgroup timelines of the two headline kernels (start / end of every workgroup, per compute unit: median / p99 / max end time) -- from the
+# diagnostic build, when the snapshot carries one (tools/mkvariant.sh trace "-DSQOA_TRACE" in the build container; its times are the
+# instrumented build's, ~40 % / 15 % longer than the product's: read the SHAPE of the distribution)
+if [ -f variants/trace.so ]; then
+    SQOA_LIB=variants/trace.so python3 tools/trace_encode.py > $out/${tag}_trace_encode.txt 2>/dev/null || true
+    SQOA_LIB=variants/trace.so python3 tools/trace_decode.py > $out/${tag}_trace_decode.txt 2>/dev/null || true
+fi
 # secondary workloads: tools/prof_kernels.py launches only the product kernels
 sec() {   # sec NAME prof_kernels-args...
     name=$1; shift
