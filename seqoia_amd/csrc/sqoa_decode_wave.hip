@@ -228,7 +228,7 @@ __global__ __launch_bounds__(DP_SCAN_THREADS) void dp_scan_pixels(const sqoa_hip
 //           pixel position and the pixel it starts from;
 //   pass 3: parse + walk + scans again, and the stores.
 // Twice the instructions of MODE 0, spread over every CU.
-template <int W, int MODE, int LB = SQOA_DEC_LB>
+template <int W, int MODE, int LB = SQOA_DEC_LB, bool SWEEP_T = false>
 __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                              const int* __restrict__ job_ids,
                                                              sqoa_hip_result* __restrict__ results,
@@ -274,6 +274,19 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
     __shared__ uint32_t s_path;  // 1 = wave path, 2 = refused
+    // The position-major store path of chunks with runs (below): per wave, the pixel of every op of the chunk by its rank in
+    // stream order (+ 64 dump words for op slots without an op), and one bit per pixel of the chunk: "an op starts here".
+#ifndef SQOA_DEC_SWEEP
+#define SQOA_DEC_SWEEP 1
+#endif
+    constexpr bool SWEEP = SQOA_DEC_SWEEP && SWEEP_T && MODE == 0;
+#ifndef SQOA_DEC_SWEEP_MIN
+#define SQOA_DEC_SWEEP_MIN 512
+#endif
+    constexpr uint32_t SWEEP_MIN_PX = SQOA_DEC_SWEEP_MIN;        // ... and must: a chunk of a few hundred pixels with a run or two in it is cheaper run by run
+    constexpr uint32_t SWEEP_PX = 4096;                          // pixels a chunk may produce on this path (longer: runs of hundreds of pixels, the fill loop's home ground)
+    __shared__ uint32_t s_swv[SWEEP ? W : 1][SWEEP ? DEC_R * 64 + 64 : 1];
+    __shared__ __attribute__((aligned(8))) uint32_t s_swb[SWEEP ? W : 1][SWEEP ? SWEEP_PX / 32 : 2];
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
@@ -765,6 +778,50 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 });
                 asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
 #endif
+            } else if (SWEEP && oc == 4 && dw_out && ctot >= SWEEP_MIN_PX && (pos_in + ctot > N ? N - pos_in : ctot) <= SWEEP_PX) {
+                // A chunk with RUNs in it, position-major.  One run at a time by the whole wave -- the path below -- is one store
+                // instruction per run (and one per literal op slot), each a few dozen dwords at whatever alignment: on icon-like
+                // streams 250 store instructions per chunk of 2000 pixels, and the stores, not the instructions around them, were
+                // two thirds of the kernel (without them: 0.58 of 1.78 ms; a run loop of a third of the instructions: no change).
+                // Here every op leaves its pixel in LDS by its rank in stream order and one bit at the pixel it starts at; then the
+                // wave sweeps the chunk's pixels 64 at a time -- the op that covers a pixel is the number of starts at or below it:
+                // a popcount of the bit row, running base in an SGPR -- and every store instruction writes 64 consecutive pixels.
+                const uint32_t total = pos_in + ctot > N ? N - pos_in : ctot;
+                uint32_t* swv = s_swv[SWEEP ? w : 0];
+                uint32_t* swb = s_swb[SWEEP ? w : 0];
+                // (the lane number, recomputed here and opaque to the compiler: with the kernel's `lane` everything below that depends
+                // on the lane alone -- the two mask words, LDS addresses -- is a loop invariant of the chunk loop, hoisted in front of
+                // it, and pays for its registers with spills of the walk's op records in the hot path: headline batch 3.12 -> 3.44 ms)
+                uint32_t lane;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+                swb[lane] = 0u; swb[lane + 64] = 0u;                                 // (4096 bits)
+                uint32_t nops = 0;
+                static_for<0, DEC_R>([&](auto i_tag) -> bool { constexpr int i = decltype(i_tag)::value; if ((uint32_t)i >= iters) return false; nops += sra31(0u - (meta[i] >> CL_BITS)) & 1u; return true; });
+                const uint32_t rank0 = wave_incl_scan(nops) - nops;                    // ops in the lanes below mine
+                const uint32_t lane_rel = cinc - cl;                                   // the chunk's pixel my first op starts at
+                static_for<0, DEC_R>([&](auto i_tag) -> bool {
+                    constexpr int i = decltype(i_tag)::value;
+                    if ((uint32_t)i >= iters) return false;
+                    const uint32_t m = meta[i], am = amask[i];
+                    const uint32_t v = add8(lane_px & ~am, val[i]);
+                    const uint32_t start = lane_rel + (m & CL_MASK);
+                    // (an op slot without an op, or an op that starts behind the image's end: its pixel to a dump word, no bit)
+                    const uint32_t on = sra31(0u - (m >> CL_BITS)) & sra31(start - total);
+                    const uint32_t idx = ((rank0 + (uint32_t)i) & on) | (((uint32_t)(DEC_R * 64) + (uint32_t)lane) & ~on);
+                    swv[idx] = v;
+                    __hip_atomic_fetch_or(&swb[(start >> 5) & (SWEEP_PX / 32 - 1) & on], (1u << (start & 31u)) & on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    return true;
+                });
+                const uint32_t lm_lo = lane < 32 ? (2u << lane) - 1u : ~0u, lm_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;   // bits 0 .. lane
+                uint32_t base = 0;                                                     // op starts in front of the 64 pixels at hand
+                gptr32 o = (gptr32)out + pos_in;
+                for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
+                    const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));   // (the same address in every lane)
+                    const uint32_t r = __builtin_popcount(bw.y & lm_hi) + __builtin_popcount(bw.x & lm_lo) + base;   // >= 1: the chunk's first op starts at its pixel 0
+                    const uint32_t v = swv[r - 1u];
+                    if (x0 + (uint32_t)lane < total) o[x0 + lane] = v;
+                    base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                }
             } else {
             auto store_ops = [&](auto oc_tag) {
                 constexpr int OC = decltype(oc_tag)::value;
@@ -875,6 +932,10 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 
 // `shape` bit 0: the plan's streams are short and many (sqoa_runtime.hip): four waves per stream instead of eight, twice as many
 // streams at once (16 384 x 128 x 128: 0.83 -> 0.73 ms, 8192 x 256 x 256: 1.83 -> 1.73 ms; 512 x 512 and up: no difference).
+// `shape` bit 2: the kernel with the position-major store path for chunks full of RUNs (decode_wave_kernel, SWEEP): icon-like streams,
+// which the plan recognises by their size -- under one stream byte per pixel -- where the jobs state the image shape.  A kernel of
+// its own because the path's registers cost the literal-op path spills: 4096 icons of 512 x 512 1.78 -> 1.50 ms with it, the
+// headline batch 3.25 -> 3.47 ms.
 // `shape` bit 1: TWELVE stream bytes per lane instead of eight (768-byte chunks).  What a chunk costs whatever its size -- the two
 // chain hops, the three wave scans, the scalar control around them: 134 of 480 VALU and most of the scalar instructions -- is
 // spread over 1.5 x the bytes; the walk keeps its eight record slots per lane (DEC_R).  Headline batch 3.41 -> 3.09 ms, icons
@@ -895,12 +956,15 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 #define SQOA_DEC_LB0 12
 #endif
     constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL, LB0 = SQOA_DEC_LB0, LB = SQOA_DEC_LB;
-    const bool small = shape & 1, wide = (shape & 2) && LB0 != LB;
-#define SQOA_DEC_LAUNCH(W_, LB_) hipLaunchKernelGGL((sqoa::decode_wave_kernel<W_, 0, LB_>), dim3(n), dim3(W_ * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u)
-    if (small && wide) SQOA_DEC_LAUNCH(WS, LB0);
-    else if (small) SQOA_DEC_LAUNCH(WS, LB);
-    else if (wide) SQOA_DEC_LAUNCH(W, LB0);
-    else SQOA_DEC_LAUNCH(W, LB);
+    const bool small = shape & 1, wide = (shape & 2) && LB0 != LB, sweep = (shape & 4) && SQOA_DEC_SWEEP;
+#define SQOA_DEC_LAUNCH(W_, LB_, SW_) hipLaunchKernelGGL((sqoa::decode_wave_kernel<W_, 0, LB_, SW_>), dim3(n), dim3(W_ * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u)
+    if (sweep) {   // (the position-major store path is there for run-heavy streams decoded to four channels: always with the wide shape)
+        if (small) SQOA_DEC_LAUNCH(WS, LB0, true); else SQOA_DEC_LAUNCH(W, LB0, true);
+    }
+    else if (small && wide) SQOA_DEC_LAUNCH(WS, LB0, false);
+    else if (small) SQOA_DEC_LAUNCH(WS, LB, false);
+    else if (wide) SQOA_DEC_LAUNCH(W, LB0, false);
+    else SQOA_DEC_LAUNCH(W, LB, false);
 #undef SQOA_DEC_LAUNCH
     return hipGetLastError();
 }

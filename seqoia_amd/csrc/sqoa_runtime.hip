@@ -115,6 +115,7 @@ struct sqoa_hip_plan {
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int wide = 0;                       // decode: every stream goes to four output channels -- the wave decoder takes twelve stream bytes per lane (sqoa_launch_decode_wave)
+    int sweep = 0;                      // decode: ... and the streams are run-heavy (under one stream byte per pixel): the kernel with the position-major store path
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
@@ -422,8 +423,22 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
             if (jobs[i].desc.channels != 4) p->wide = 0;
         }
+        // (streams of a few kilobytes are a handful of chunks either way, and fewer, larger ones leave waves of the workgroup idle:
+        // 4096 icons of 128 x 128, 4 KB each, 0.130 -> 0.140 ms with twelve bytes per lane; 256 x 256, 16 KB: 0.516 -> 0.508 ms)
+        if (bytes / ids_a.size() < (12u << 10)) p->wide = 0;
         // (SQOA_HIP_DEC_WIDE=0 / =1 in the environment: never / always -- tests and measurements; the results are the same)
         if (const char* kw = getenv("SQOA_HIP_DEC_WIDE")) p->wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : p->wide;
+        // Run-heavy streams (icons, screenshots: a stream byte stands for several pixels) take the kernel whose store path writes
+        // 64 consecutive pixels per instruction instead of a store per run (sqoa_launch_decode_wave).  What the plan can see of a
+        // stream's content is its size against the image's -- where the jobs state the shape they expect: under one stream byte per
+        // pixel over the whole plan.  (SQOA_HIP_DEC_SWEEP=0 / =1 forces it: tests and measurements.)
+        {
+            unsigned long long px = 0;
+            bool shaped = true;
+            for (int i : ids_a) { px += (unsigned long long)jobs[i].desc.width * jobs[i].desc.height; if (!jobs[i].desc.width || !jobs[i].desc.height) shaped = false; }
+            p->sweep = p->wide && shaped && bytes < px;
+            if (const char* ks = getenv("SQOA_HIP_DEC_SWEEP")) p->sweep = ks[0] == '1' ? p->wide : ks[0] == '0' ? 0 : p->sweep;
+        }
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
@@ -622,7 +637,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small | p->wide << 1, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small | p->wide << 1 | p->sweep << 2, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }
