@@ -778,7 +778,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 });
                 asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
 #endif
-            } else if (SWEEP && oc == 4 && dw_out && ctot >= SWEEP_MIN_PX && (pos_in + ctot > N ? N - pos_in : ctot) <= SWEEP_PX) {
+            } else if (SWEEP && ((oc == 4 && dw_out) || oc == 3) && ctot >= SWEEP_MIN_PX && (pos_in + ctot > N ? N - pos_in : ctot) <= SWEEP_PX) {
                 // A chunk with RUNs in it, position-major.  One run at a time by the whole wave -- the path below -- is one store
                 // instruction per run (and one per literal op slot), each a few dozen dwords at whatever alignment: on icon-like
                 // streams 250 store instructions per chunk of 2000 pixels, and the stores, not the instructions around them, were
@@ -812,15 +812,44 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     __hip_atomic_fetch_or(&swb[(start >> 5) & (SWEEP_PX / 32 - 1) & on], (1u << (start & 31u)) & on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     return true;
                 });
-                const uint32_t lm_lo = lane < 32 ? (2u << lane) - 1u : ~0u, lm_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;   // bits 0 .. lane
                 uint32_t base = 0;                                                     // op starts in front of the 64 pixels at hand
-                gptr32 o = (gptr32)out + pos_in;
-                for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
-                    const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));   // (the same address in every lane)
-                    const uint32_t r = __builtin_popcount(bw.y & lm_hi) + __builtin_popcount(bw.x & lm_lo) + base;   // >= 1: the chunk's first op starts at its pixel 0
-                    const uint32_t v = swv[r - 1u];
-                    if (x0 + (uint32_t)lane < total) o[x0 + lane] = v;
-                    base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                if (oc == 4) {
+                    const uint32_t lm_lo = lane < 32 ? (2u << lane) - 1u : ~0u, lm_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;   // bits 0 .. lane
+                    gptr32 o = (gptr32)out + pos_in;
+                    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
+                        const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));   // (the same address in every lane)
+                        const uint32_t r = __builtin_popcount(bw.y & lm_hi) + __builtin_popcount(bw.x & lm_lo) + base;   // >= 1: the chunk's first op starts at its pixel 0
+                        const uint32_t v = swv[r - 1u];
+                        if (x0 + (uint32_t)lane < total) o[x0 + lane] = v;
+                        base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                    }
+                } else {
+                    // Three channels: the 64 pixels of a step are 192 bytes = 48 dwords (at whatever alignment 3 * pos_in has: unaligned
+                    // dword stores are fine), dword j = the bytes 4 j .. 4 j + 3 of the step = the tail of pixel pa = j + j / 3 and the
+                    // head of pixel pa + 1, i.e. the six bytes rgb(pa) rgb(pa + 1) shifted by j mod 3 bytes.
+                    const uint32_t pa = lane + ((lane * 171u) >> 9), ph = lane - 3u * ((lane * 171u) >> 9);   // (lane < 48 where it counts: pa <= 62)
+                    const uint32_t la_lo = pa < 32u ? (2u << pa) - 1u : ~0u, la_hi = pa < 32u ? 0u : (2u << (pa - 32u)) - 1u;   // bits 0 .. pa
+                    const uint32_t pb = pa + 1u;                                           // <= 63
+                    typedef uint32_t u32_una __attribute__((aligned(1)));
+                    typedef __attribute__((address_space(1))) u32_una* gptr32u;
+                    gptr8 ob = out + (size_t)pos_in * 3u;
+                    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
+                        const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));
+                        const uint32_t ra = __builtin_popcount(bw.y & la_hi) + __builtin_popcount(bw.x & la_lo) + base;
+                        const uint32_t rb = ra + (((pb < 32u ? bw.x : bw.y) >> (pb & 31u)) & 1u);
+                        const uint32_t va = swv[ra - 1u] & 0x00ffffffu, vb = swv[rb - 1u];
+                        const uint32_t d = __builtin_amdgcn_alignbyte((vb >> 8) & 0xffffu, va | vb << 24, ph);
+                        const uint32_t left = 3u * (total - x0);                           // bytes of the chunk from this step on
+                        const uint32_t b0 = 4u * lane;
+                        if (lane < 48u && b0 + 4u <= left) *(gptr32u)(ob + 3u * x0 + b0) = d;
+                        else if (lane < 48u && b0 < left) {                                // the chunk's last one to three bytes
+                            gptr8 q = ob + 3u * x0 + b0;
+                            q[0] = (uint8_t)d;
+                            if (b0 + 1u < left) q[1] = (uint8_t)(d >> 8);
+                            if (b0 + 2u < left) q[2] = (uint8_t)(d >> 16);
+                        }
+                        base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                    }
                 }
             } else {
             auto store_ops = [&](auto oc_tag) {
@@ -958,7 +987,7 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
     constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL, LB0 = SQOA_DEC_LB0, LB = SQOA_DEC_LB;
     const bool small = shape & 1, wide = (shape & 2) && LB0 != LB, sweep = (shape & 4) && SQOA_DEC_SWEEP;
 #define SQOA_DEC_LAUNCH(W_, LB_, SW_) hipLaunchKernelGGL((sqoa::decode_wave_kernel<W_, 0, LB_, SW_>), dim3(n), dim3(W_ * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 0u, 0u)
-    if (sweep) {   // (the position-major store path is there for run-heavy streams decoded to four channels: always with the wide shape)
+    if (sweep) {   // (the position-major store path is there for run-heavy streams decoded to three or four channels: always with the wide shape)
         if (small) SQOA_DEC_LAUNCH(WS, LB0, true); else SQOA_DEC_LAUNCH(W, LB0, true);
     }
     else if (small && wide) SQOA_DEC_LAUNCH(WS, LB0, false);

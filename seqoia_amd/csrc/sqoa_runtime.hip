@@ -434,10 +434,13 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         // pixel over the whole plan.  (SQOA_HIP_DEC_SWEEP=0 / =1 forces it: tests and measurements.)
         {
             unsigned long long px = 0;
-            bool shaped = true;
-            for (int i : ids_a) { px += (unsigned long long)jobs[i].desc.width * jobs[i].desc.height; if (!jobs[i].desc.width || !jobs[i].desc.height) shaped = false; }
-            p->sweep = p->wide && shaped && bytes < px;
-            if (const char* ks = getenv("SQOA_HIP_DEC_SWEEP")) p->sweep = ks[0] == '1' ? p->wide : ks[0] == '0' ? 0 : p->sweep;
+            bool shaped = true;   // ... and every job asks for 3 or 4 channels (the path's two store forms)
+            for (int i : ids_a) {
+                px += (unsigned long long)jobs[i].desc.width * jobs[i].desc.height;
+                if (!jobs[i].desc.width || !jobs[i].desc.height || jobs[i].desc.channels < 3) shaped = false;
+            }
+            p->sweep = shaped && bytes < px && bytes / ids_a.size() >= (12u << 10);
+            if (const char* ks = getenv("SQOA_HIP_DEC_SWEEP")) p->sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : p->sweep;
         }
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");

@@ -811,3 +811,51 @@ def test_lone_large_qoi_stream_is_decoded_by_the_whole_chip(sq, orc, cls, ch):
     assert ms < 2.0, ms
     dec.close()
     enc.close()
+
+
+@pytest.mark.parametrize("knob", ["plan", "1", "0"])
+def test_run_heavy_streams_take_the_position_major_store_path(sq, orc, monkeypatch, knob):
+    """Icon-like streams (BASELINE configs[3]: RUN-heavy) to 3 and to 4 channels: chunks that are full of runs store their pixels 64
+    consecutive ones per instruction (sqoa_decode_wave.hip, SWEEP) -- the plan's own choice for streams of under one byte per
+    pixel, forced on, forced off: the pixels are the reference's (seqoia.h:723-725, :790-805) every time.  Streams built around
+    the path's edges: runs across chunk boundaries, chunks of more pixels than the path takes (runs of hundreds: the fill loop),
+    an image that ends inside a chunk whose runs overshoot it, 3-byte output at every alignment of its first byte."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(99)
+    if knob != "plan":
+        monkeypatch.setenv("SQOA_HIP_DEC_SWEEP", knob)
+    cases = []   # (stream bytes, w, h)
+    for k, (w, h, ch) in enumerate(((256, 256, 3), (256, 256, 4), (511, 130, 4), (640, 97, 3))):
+        px = orc.synth(w, h, ch, "icon", 11, k)
+        cases.append((o.encode(px, w, h, ch, 0), w, h))
+    # hand-made: rows of short runs of random colours with literal ops in between, long runs, one huge run
+    def hdr(w, h, ch=4):
+        return b"Sqoa" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0, 0x31])
+    END = bytes(7) + b"\x01"
+    body = bytearray()
+    for _ in range(6000):
+        body += bytes([0xfe]) + bytes(rng.integers(0, 256, 3).tolist()) + bytes([0xc0 | int(rng.integers(0, 40))])
+        if rng.integers(0, 4) == 0:
+            body += bytes([0x80 | int(rng.integers(0, 64)), int(rng.integers(0, 256))])
+        if rng.integers(0, 50) == 0:
+            body += b"\xfd" * int(rng.integers(1, 6)) + bytes([0xc0 | int(rng.integers(0, 61))])
+    cases.append((hdr(700, 300) + bytes(body) + END, 700, 300))          # ends inside the stream: ops behind the image's end
+    cases.append((hdr(900, 400) + bytes(body) + END, 900, 400))          # the stream ends early: the last pixel repeats
+    cases.append((hdr(640, 480) + bytes(body[:3000]) + b"\xfd" * 700 + END, 640, 480))
+    for oc in (3, 4):
+        for stream, w, h in cases:
+            want, _ = o.decode(stream, oc)
+            for shift in ((0,) if oc == 4 else (0, 1, 2, 3)):           # byte address of the first pixel, mod 4
+                buf = torch.zeros((len(stream) + 64,), dtype=torch.uint8, device="cuda")
+                buf[: len(stream)] = torch.frombuffer(bytearray(stream), dtype=torch.uint8).cuda()
+                arena = torch.zeros((w * h * oc + 64,), dtype=torch.uint8, device="cuda")
+                out = arena[shift : shift + w * h * oc].view(1, h, w, oc)
+                dec = sq.DecodePlan(buf[: len(stream)].view(1, -1), [len(stream)], w, h, oc, out=out)
+                dec.launch()
+                res = dec.results()
+                assert res["status"][0] == 0, (oc, w, h, shift)
+                assert bytes(dec.out.reshape(-1).cpu().numpy()) == want.tobytes(), (oc, w, h, shift, knob)
+                assert int(arena[shift + w * h * oc :].max()) == 0 and (shift == 0 or int(arena[:shift].max()) == 0), "wrote outside the image"
+                dec.close()
