@@ -334,6 +334,25 @@ class Suite:
         self.enc.close()
 
 
+def board_power():
+    """(watts drawn, the cap, shader clock in MHz) of the busiest card the host shows in sysfs hwmon -- the one this process loads, unless a
+    neighbour on the same host is busier -- or None.  Both kernels run AT the board's power cap on MI355X (1400 W: profiles/r04_power.txt;
+    the clock the chip then holds is what `roofline.*.clock_ghz` reports from the SQ counters): one read, a few microseconds."""
+    import glob
+
+    best = None
+    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        try:
+            w = int(open(os.path.join(h, "power1_input")).read()) / 1e6
+            cap = int(open(os.path.join(h, "power1_cap")).read()) / 1e6
+            mhz = int(open(os.path.join(h, "freq1_input")).read()) / 1e6
+        except (OSError, ValueError):
+            continue
+        if best is None or w > best[0]:
+            best = (round(w, 1), round(cap, 1), round(mhz))
+    return best
+
+
 def kernel_times(wl, k):
     """(encode ms, decode ms) per launch, HIP events on the plans' own stream."""
     return wl.enc.time(k) / k, wl.dec.time(k) / k
@@ -346,7 +365,7 @@ def secondary(sq, torch, dev, headline, k=5):
     fraction = channels B/px / encode time / 8 TB/s; decode fraction = (stream + pixel bytes) / time / 8 TB/s."""
     out = {}
 
-    def row(name, wl):
+    def row(name, wl, four=False):
         wl.enc.time(2), wl.dec.time(2)
         e, d = kernel_times(wl, k)
         out[name] = {
@@ -356,6 +375,18 @@ def secondary(sq, torch, dev, headline, k=5):
             "encode_read_roofline_frac": round(wl.read_bytes / e / 1e6 / HBM_PEAK_GBS, 4),
             "decode_roofline_frac": round((wl.enc_bytes + wl.write_bytes) / d / 1e6 / HBM_PEAK_GBS, 4),
         }
+        if four:
+            # sqoabench's TIMED decode asks for 4 channels whatever the file holds (sqoabench.c:490-494; its verify decode, :448-455,
+            # asks for the file's own count: `decode_ms` above): the same streams to RGBA, checked against the pixels they came from
+            nn, hh, ww, cc = wl.px.shape
+            d4 = sq.DecodePlan(wl.enc.out, wl.lens, ww, hh, 4)
+            d4.launch()
+            assert (d4.results()["status"] == 0).all() and torch.equal(d4.out[..., :cc], wl.px) and bool((d4.out[..., 3] == 255).all()), "4-channel decode mismatch"
+            d4.time(2)
+            t4 = d4.time(k) / k
+            out[name].update({"decode_to_4_channels_ms": round(t4, 4), "decode_to_4_channels_mpps": round(wl.pixels / t4 / 1e3, 1),
+                              "decode_to_4_channels_roofline_frac": round((wl.enc_bytes + wl.pixels * 4) / t4 / 1e6 / HBM_PEAK_GBS, 4)})
+            d4.close()
         wl.close()
 
     h = headline
@@ -373,7 +404,7 @@ def secondary(sq, torch, dev, headline, k=5):
     row(f"qoi_compat=1, {n} x {ww}x{hh} RGBA (the headline batch)", wl)
     for size in (512, 64):
         for qoi in (0, 1):
-            row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi))
+            row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi), four=True)
     # few large images: the plan cuts them into strips on the device (encode) / decodes them in three chip-wide passes
     # (DESIGN.md 3.1b, 3.2b); one workgroup per image would be one compute unit's speed (0.57 / 2.0 ms per Mpixel)
     row("one 3840x2160 RGBA image alone, qoi_compat=0", Uniform(sq, torch, dev, 1, 3840, 2160, 4, "mixed", 0))
@@ -582,6 +613,7 @@ def run_rank(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    power = board_power()   # (read while the last steps are still running on the device: the launches above are asynchronous)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -637,6 +669,8 @@ def run_rank(args):
             "launch": "hip graph replay" if graph is not None else "direct",
             "spin_up_ms_per_step": [spin_ms[0], min(spin_ms), spin_ms[-1]],  # first group of 8, fastest, last
             "spin_up_steps": spin_up,  # untimed, in front of the W warm-up steps: the clocks ramp up after the idle setup phase
+            # board power / its cap / shader clock read from sysfs while the last timed steps ran (rank 0's host view; None where hwmon is not readable)
+            "board_power_w": power[0] if power else None, "board_power_cap_w": power[1] if power else None, "sclk_mhz_hwmon": power[2] if power else None,
             "encode_mpps_rank0": round(wl.pixels / enc_ms / 1e3, 1),
             "decode_mpps_rank0": round(wl.pixels / dec_ms / 1e3, 1),
             "roofline_frac_of_n_gpus": round(total_px * args.steps / dt / (world * HBM_PEAK_GBS * 1e9 / 4), 4),

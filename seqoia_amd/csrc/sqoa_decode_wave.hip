@@ -46,6 +46,7 @@ constexpr int DEC_CHUNK = DEC_LB * 64;         // stream bytes per chunk (one wa
 // that its predecessor did, writes the abort tag into its OWN three chain words and leaves; every wave waits on its
 // predecessor's words sooner or later, so the news goes round the ring), the spin limit a down-counter.
 constexpr uint32_t DEC_ABORT_TAG = 0xffffffffu;   // (chunk tags are chunk numbers + 1 < 2^32 - 1)
+template <int SLEEP = SQOA_DEC_SPIN_SLEEP>
 SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t& val) {
 #ifdef SQOA_DEC_C_POLL   // the loop as the compiler makes it (A/B builds)
     uint32_t left = DEC_SPIN_MAX;
@@ -55,10 +56,10 @@ SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t
         if (t == tag) { val = bcast_first((uint32_t)v); return 0u; }
         if (t == DEC_ABORT_TAG) return 1u;
         if (--left == 0u) return 2u;
-        __builtin_amdgcn_s_sleep(SQOA_DEC_SPIN_SLEEP);
+        __builtin_amdgcn_s_sleep(SLEEP);
     }
 #else
-    const uint32_t t = chain_poll<SQOA_DEC_SPIN_SLEEP>(slot, tag, DEC_ABORT_TAG, val);
+    const uint32_t t = chain_poll<SLEEP>(slot, tag, DEC_ABORT_TAG, val);
     return t == tag ? 0u : t == DEC_ABORT_TAG ? 1u : 2u;
 #endif
 }
@@ -248,6 +249,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 #define SQOA_DEC_R16 10
 #endif
     constexpr int DEC_R = LB < 8 ? LB : LB <= 12 ? 8 : SQOA_DEC_R16;
+    // s_sleep argument (x 64 cycles) between two looks at a chain word: the 768-byte chunks of the batch shape take longer, and a
+    // waiting wave that looks less often leaves the LDS and scalar pipes to the others (3.117 -> 3.092 ms at 4 against 1; the passes
+    // and the 512-byte shape keep 1: a lone stream's chains are its critical path)
+#ifndef SQOA_DEC_SPIN_SLEEP_WIDE
+#define SQOA_DEC_SPIN_SLEEP_WIDE 4
+#endif
+    constexpr int SPIN = (MODE == 0 && LB > 8) ? SQOA_DEC_SPIN_SLEEP_WIDE : SQOA_DEC_SPIN_SLEEP;
     constexpr int CL_BITS = DEC_R <= 8 ? 13 : 14;                         // pixels in front of an op inside its lane: at most DEC_R - 1 ops of at most 1024 pixels
     constexpr uint32_t CL_MASK = (1u << CL_BITS) - 1u;
     static_assert(MODE == 0 || LB == sqoa::DEC_LB, "the passes run at the chunk size the plan lays the tables out for");
@@ -278,6 +286,9 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     // stream order (+ 64 dump words for op slots without an op), and one bit per pixel of the chunk: "an op starts here".
 #ifndef SQOA_DEC_SWEEP
 #define SQOA_DEC_SWEEP 1
+#endif
+#ifndef SQOA_DEC_EXEC_WALK
+#define SQOA_DEC_EXEC_WALK 1
 #endif
     constexpr bool SWEEP = SQOA_DEC_SWEEP && SWEEP_T && MODE == 0;
 #ifndef SQOA_DEC_SWEEP_MIN
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             const bool early = g_const && MODE != 2;
             if (early && !last_chunk) post(my_parse, c + 1, g0, lane);
             if (c > chunk_first) {
-                const uint32_t rc = chain_wait_rc(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in);
+                const uint32_t rc = chain_wait_rc<SPIN>(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in);
                 if (rc) { bad |= rc >> 1; return 0u; }
             }
             if (!early && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
@@ -640,6 +651,45 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 iters = i;
                 return false;
             }
+#if SQOA_DEC_EXEC_WALK
+            // Lanes that have run out of ops sit the iteration out under EXEC (a lane never comes back: its position only grows), not
+            // as lanes that decode a "no op" table entry behind arithmetic masks.  The chip runs this kernel AT its power limit (1400 W
+            // board power, the clock falls until it fits: profiles/r04_power.txt), a third of the walk's lane slots are such lanes (the
+            // iteration count is the busiest lane's), and what an idle lane does not execute it does not pay for.
+            asm volatile("" : "=v"(val[i]), "=v"(amask[i]));   // (read later only where meta says the slot holds an op)
+            meta[i] = cl;                                      // no op in this slot of mine: zero pixels
+            if (pos < nlive) {
+            uint32_t lo, hi;
+            window(lane_addr + pos, lo, hi);
+            const u32x4 e = *(lcptr128)(uintptr_t)(optab_addr + (lo & 0xffu) * 16u);
+            info_or |= e.x;
+            const uint32_t len = e.x & 7u, setm = e.y;
+            uint32_t cnt = (e.x >> 9) & 0x3ffu;
+            // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op.  w1 = stream >> (8 * len - 4).
+            const unsigned long long q = (unsigned long long)hi << 32 | lo;
+            const uint32_t w1 = (uint32_t)(q >> ((e.x >> 3) & 63u));
+            const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 >> 1) & 0x7f8u));
+            const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
+            const uint32_t adv = len + (se & 1u);
+            // A RUN right behind an op repeats exactly the pixel this op produces: taken in the same iteration (see below)
+            const uint32_t w2 = w1 >> has8;
+            const uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
+            const uint32_t m_nsfx = *(lcptr32)(uintptr_t)(sfx_addr + 4u + ((w2 >> 9) & 0x7f8u));          // ~0 unless an ALPHA byte follows
+            const uint32_t m_fuse = m_nsfx & sra31(pos + adv - nlive) & sra31(cnt + extra - 1025u);
+            const uint32_t extra_m = extra & m_fuse;
+            cnt += extra_m;
+            const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
+            const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;                         // LUMA, seqoia.h:761-769
+            const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
+            T = xf_then(T, Xf{(d8 & ~setm) | (base & setm), setm} HLARG);
+            val[i] = T.v;
+            meta[i] = cl | cnt << CL_BITS;
+            amask[i] = T.abs;
+            cl += cnt;
+            longest = longest > cnt ? longest : cnt;
+            pos += adv + ((extra_m + 1023u) >> 10);
+            }
+#else
             // The op decode of seqoia.h:740-783 as table look-ups and mask arithmetic; no compare / select pairs.
             const uint32_t m_act = sra31(pos - nlive);                     // ~0 while I still have an op (pos < nlive <= 8)
             uint32_t lo, hi;
@@ -685,6 +735,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
             cl += cnt;
             longest = longest > cnt ? longest : cnt;
             pos += adv + ((extra_m + 1023u) >> 10);
+#endif
             sfx_ok = false;  // the suffix after an op is consumed with the op; the next byte is an op start
             return true;
         });
@@ -718,7 +769,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         if (c > chunk_first) {
             // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
             // instructions in order), so it is there when the pixel word's tag is
-            const uint32_t rc = chain_wait_rc(&s_px[(c - 1) % W], c, px_in);
+            const uint32_t rc = chain_wait_rc<SPIN>(&s_px[(c - 1) % W], c, px_in);
             if (rc) { bad |= rc >> 1; return 0u; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             pos_in = bcast_first((uint32_t)__hip_atomic_load(&s_pos[(c - 1) % W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
