@@ -493,6 +493,19 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
         for (int i = 0; i < QK_LB; ++i) {
             if (__ballot(pos < nlive) == 0ull) { iters = i; break; }
+#if defined(SQOA_QDEC_EXEC_WALK) && SQOA_QDEC_EXEC_WALK
+            // (A/B builds: lanes that have run out of ops sit the iteration out under EXEC, as in decode_wave_kernel -- which runs at the
+            // board's power limit and gained 4 % from it.  This kernel waits for its resolver, not for its power budget, and the EXEC
+            // bookkeeping is scalar instructions on a scalar pipe that is full: 9.45 -> 9.66 ms.  Off.)
+            asm volatile("" : "=v"(rv[i]));   // (read later only where rm says the slot holds an op)
+            rm[i] = 0u;
+            if (pos >= nlive) continue;
+            const uint32_t a = lane_addr + pos;
+            lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+            const u32x4 e = *(lcptr128)(uintptr_t)(qtab_addr + (lo & 0xffu) * 16u);
+#else
             const uint32_t m_act = sra31(pos - nlive);                      // ~0 while I still have an op (pos < nlive <= 8)
             const uint32_t a = lane_addr + ((pos & m_act) | ((uint32_t)QK_LB & ~m_act));
             lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
@@ -500,6 +513,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
             const uint32_t idx = (((lo & 0xffu) - 256u) & m_act) + 256u;    // lanes out of ops decode the "no op" entry
             const u32x4 e = *(lcptr128)(uintptr_t)(qtab_addr + idx * 16u);
+#endif
             const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;     // LUMA: dr_dg, db_dg (seqoia.h:765-768)
             const uint32_t rel = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u);
             const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8);                     // RGB / RGBA: the bytes behind the op byte
