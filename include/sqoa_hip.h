@@ -121,8 +121,10 @@ int sqoa_hip_memcpy_d2h_async(int device, void *dst, unsigned long long src, siz
  * must be mapped, readable device memory when sqoa_hip_plan_create / sqoa_hip_plan_update is called (its CONTENT may still be
  * on its way from a producer on another stream: the read is one byte, on the plan's own stream, and not ordered against anybody;
  * what it sees only steers the hint).  Jobs flagged SQOA_HIP_JOB_WAVEONLY are never read at fill time.
- * A decode plan whose every job asks for 4 output channels runs the wave decoder with twelve stream bytes per lane instead of
- * eight; SQOA_HIP_DEC_WIDE=0 / =1 in the environment forces the one or the other (tests, measurements). */
+ * A decode plan whose 4-channel jobs carry most of its stream bytes runs the wave decoder with twelve stream bytes per lane instead
+ * of eight, and one of run-heavy streams (under a stream byte per pixel, where the jobs state width and height) the kernel variant
+ * that stores 64 consecutive pixels per instruction; SQOA_HIP_DEC_WIDE / SQOA_HIP_DEC_SWEEP = 0 / 1 in the environment
+ * force the one or the other (tests, measurements; the decoded bytes are the same). */
 /* The choice a decode plan makes, as a pure host function (no device needed): order[0 .. *n_multipass) = the streams that take
  * the three passes, largest first; order[*n_multipass .. n) = the dispatch order of the streams that get a workgroup each
  * (largest first, every second run of `cus` reversed so that the compute units' loads even out).  `src_sizes[i]` = stream

@@ -534,7 +534,8 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
 // streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel.
-// `shape`: bit 0 = many short streams, bit 1 = every stream is decoded to four channels, bit 2 = ... and they are run-heavy (sqoa_launch_decode_wave)
+// `shape`: the wave decoder's shape for the streams that get a workgroup each -- bit 0 = many short streams, bit 1 = twelve stream bytes per
+// lane, bit 2 = the position-major store path (sqoa_launch_decode_wave; the plan decides, sqoa_runtime.hip)
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

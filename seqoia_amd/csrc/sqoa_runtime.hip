@@ -114,8 +114,8 @@ struct sqoa_hip_plan {
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
     int n_sqoa_small = 0, n_qoi_small = 0;   // encode: how many at the end of each list are small images that get one wave each
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
-    int wide = 0;                       // decode: every stream goes to four output channels -- the wave decoder takes twelve stream bytes per lane (sqoa_launch_decode_wave)
-    int sweep = 0;                      // decode: ... and the streams are run-heavy (under one stream byte per pixel): the kernel with the position-major store path
+    int shape = 0;                      // decode, the streams that get a workgroup each: the wave decoder's shape (sqoa_launch_decode_wave) -- bit 0 = many short
+                                        // streams, bit 1 = 12 stream bytes per lane, bit 2 = position-major stores
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
@@ -418,30 +418,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         for (size_t k = 0; k < ids_a.size(); ++k) { sizes[k] = jobs[ids_a[k]].src_size; bytes += sizes[k]; }
         p->small = ids_a.size() > 2048 && bytes / ids_a.size() < (256u << 10);
         p->wave_only = 1;
-        p->wide = 1;
-        for (int i : ids_a) {
-            if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
-            if (jobs[i].desc.channels != 4) p->wide = 0;
-        }
-        // (streams of a few kilobytes are a handful of chunks either way, and fewer, larger ones leave waves of the workgroup idle:
-        // 4096 icons of 128 x 128, 4 KB each, 0.130 -> 0.140 ms with twelve bytes per lane; 256 x 256, 16 KB: 0.516 -> 0.508 ms)
-        if (bytes / ids_a.size() < (12u << 10)) p->wide = 0;
-        // (SQOA_HIP_DEC_WIDE=0 / =1 in the environment: never / always -- tests and measurements; the results are the same)
-        if (const char* kw = getenv("SQOA_HIP_DEC_WIDE")) p->wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : p->wide;
-        // Run-heavy streams (icons, screenshots: a stream byte stands for several pixels) take the kernel whose store path writes
-        // 64 consecutive pixels per instruction instead of a store per run (sqoa_launch_decode_wave).  What the plan can see of a
-        // stream's content is its size against the image's -- where the jobs state the shape they expect: under one stream byte per
-        // pixel over the whole plan.  (SQOA_HIP_DEC_SWEEP=0 / =1 forces it: tests and measurements.)
-        {
-            unsigned long long px = 0;
-            bool shaped = true;   // ... and every job asks for 3 or 4 channels (the path's two store forms)
-            for (int i : ids_a) {
-                px += (unsigned long long)jobs[i].desc.width * jobs[i].desc.height;
-                if (!jobs[i].desc.width || !jobs[i].desc.height || jobs[i].desc.channels < 3) shaped = false;
-            }
-            p->sweep = shaped && bytes < px && bytes / ids_a.size() >= (12u << 10);
-            if (const char* ks = getenv("SQOA_HIP_DEC_SWEEP")) p->sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : p->sweep;
-        }
+        for (int i : ids_a) if (!(jobs[i].reserved & SQOA_HIP_JOB_WAVEONLY)) p->wave_only = 0;
         // SQOA_HIP_MULTIPASS=0 / =1 in the environment: never / every stream (tests and measurements; the results are the same)
         const char* knob = getenv("SQOA_HIP_MULTIPASS");
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
@@ -453,6 +430,41 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
         ids_a.swap(sorted);
         n_multi_dec = n_multi;   // (their tables: below, once the job table is on the device)
+        // The streams that get a workgroup each: which shape of the wave decoder (sqoa_launch_decode_wave)?  What the plan can see
+        // without reading a stream is what the jobs say -- output channels, image shape -- and the streams' sizes:
+        //  * 12 stream bytes per lane instead of 8 ("wide") when the streams that go to FOUR channels are three quarters of the launch's
+        //    bytes or more (to three channels the byte stores are the bound and the wide shape loses 9 % where to four it gains as much:
+        //    BASELINE configs[4]'s rank shard, 83 % four-channel bytes, 12.11 -> 11.38 ms) and the streams are not tiny (a few kilobytes are a handful of chunks
+        //    either way, and fewer, larger ones leave waves idle: 4096 icons of 128 x 128, 4 KB each, 0.130 -> 0.140 ms; 16 KB: 0.516 -> 0.508);
+        //  * the kernel with the position-major store path ("sweep") for RUN-heavy streams to 3 or 4 channels: under one stream byte
+        //    per pixel over the launch, where the jobs state the shapes they expect.
+        // (A plan of mixed channel counts as two launches, the four-channel jobs first with their own shape, was measured on BASELINE
+        // configs[4]'s rank shard -- 557 RGB photos among 7 635 RGBA images -- and lost, 12.11 -> 12.37 ms: the second launch's streams
+        // no longer share the chip with the first's.  One launch, one shape.)
+        // (SQOA_HIP_DEC_WIDE / SQOA_HIP_DEC_SWEEP = 0 / 1 in the environment force either: tests and measurements; the results are the same.)
+        {
+            const size_t c0 = (size_t)n_multi;
+            const char* kw = getenv("SQOA_HIP_DEC_WIDE");
+            const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
+            auto shape_of = [&](size_t a, size_t b) -> int {
+                if (a >= b) return 0;
+                unsigned long long by = 0, by4 = 0, px = 0;
+                bool shaped = true;
+                for (size_t k = a; k < b; ++k) {
+                    const sqoa_hip_job& j = jobs[ids_a[k]];
+                    by += j.src_size;
+                    px += (unsigned long long)j.desc.width * j.desc.height;
+                    if (j.desc.channels == 4) by4 += j.src_size;
+                    if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
+                }
+                const bool roomy = by / (b - a) >= (12u << 10);
+                int wide = roomy && 4u * by4 >= 3u * by, sweep = shaped && roomy && by < px;
+                if (kw) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
+                if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
+                return p->small | wide << 1 | sweep << 2;
+            };
+            p->shape = shape_of(c0, ids_a.size());
+        }
     }
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
@@ -640,7 +652,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->small | p->wide << 1 | p->sweep << 2, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }
