@@ -28,6 +28,7 @@ struct sqoa_dp_tables {
     void* d_qstate;                 // two decoder states (pixel + colour index, 512 bytes each) per workgroup row: the speculative pass of QOI-compat streams
     int any_qoi;                    // a HINT, taken when the plan was filled: some of these streams are in QOI-compat framing (0: the speculative pass and its check are not launched)
     int cus;                        // compute units of the plan's device
+    int lb;                         // stream bytes per lane of the passes (8, or 12 for plans without a QOI-compat stream among these: the speculative pass counts 512-byte chunks)
 };
 
 // Tables of the strip encode of few large images (sqoa_strips.hip); built by the plan (sqoa_runtime.hip).

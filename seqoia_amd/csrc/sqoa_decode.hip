@@ -529,7 +529,7 @@ extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sq
                                                   const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
                                                   int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, hipStream_t stream);
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, int lb, hipStream_t stream);
 
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
@@ -548,10 +548,10 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
 #define SQOA_DP_FUSE_ROWS 1024   /* (a lone 1 Mpixel stream, 670 rows: 0.0355 -> 0.032 ms; 2594 rows, one 3840 x 2160 stream: equal; 64 x 1 Mpixel, 5184 rows: 0.517 -> 0.531 ms) */
 #endif
     const int scans = n_multi && ((!wave_only && dp->any_qoi) || dp->n_wgs > SQOA_DP_FUSE_ROWS);
-    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, scans, stream);
+    if (n_multi) e = sqoa_launch_decode_passes(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags, dp->per, scans, dp->lb, stream);
     if (e != hipSuccess) return e;
     // the QOI-compat streams among them: speculative chip-wide pass + check (sqoa_decode_qoi.hip); what fails the check stays SLOWPATH
-    if (n_multi && !wave_only && dp->any_qoi) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,
+    if (n_multi && !wave_only && dp->any_qoi && dp->lb != 12) e = sqoa_launch_decode_qoi_spec(d_jobs, d_results, dp->d_images, dp->n_images, dp->d_wgs, dp->n_wgs, dp->d_tab, dp->d_flags,
                                                                dp->d_qstate, dp->per, dp->cus, stream);
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi, shape, d_results, stream);

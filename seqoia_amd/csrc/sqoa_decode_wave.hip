@@ -258,7 +258,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     constexpr int SPIN = (MODE == 0 && LB > 8) ? SQOA_DEC_SPIN_SLEEP_WIDE : SQOA_DEC_SPIN_SLEEP;
     constexpr int CL_BITS = DEC_R <= 8 ? 13 : 14;                         // pixels in front of an op inside its lane: at most DEC_R - 1 ops of at most 1024 pixels
     constexpr uint32_t CL_MASK = (1u << CL_BITS) - 1u;
-    static_assert(MODE == 0 || LB == sqoa::DEC_LB, "the passes run at the chunk size the plan lays the tables out for");
+    // (the passes, MODE 1..3, run at the chunk size the plan laid their tables out for: sqoa_dp_tables.lb)
     static_assert(LB % 4 == 0 && (DEC_R - 1) * 1024 <= (int)CL_MASK, "bytes per lane");
     __shared__ uint32_t s_bytes[W][DEC_LDS_DW];
     __shared__ uint32_t s_ftab[256];  // byte -> low half of its transition function (live bytes)
@@ -1052,7 +1052,7 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
 // Few large streams: three passes over all their chunks with the whole chip (see decode_wave_kernel), two one-wave-per-image scans
 // in between.  `d_images` / `d_wgs` / `d_tab` / `d_flags`: the tables the plan built (sqoa_runtime.hip).
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
-                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, hipStream_t stream) {
+                                                const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, int lb, hipStream_t stream) {
     if (n_images <= 0 || n_wgs <= 0) return hipSuccess;
     if (per < sqoa::DP_CHUNKS_PER_WG_MIN || per > sqoa::DP_CHUNKS_PER_WG_MAX || per % 8u) return hipErrorInvalidValue;   // (8 waves take the chunks round-robin)
     using namespace sqoa;
@@ -1064,11 +1064,19 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
     // (no initialisation of the flags: pass 1's first workgroup of every image writes its flag before anything reads it)
     // `scans` = 0: no scan kernels, the workgroups of passes 2 and 3 compose the rows in front of them by themselves (see the kernel)
     const uint32_t fused = scans ? 0u : 1u;
-    hipLaunchKernelGGL((decode_wave_kernel<W, 1>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, 0u);
-    if (scans) hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 2>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
-    if (scans) hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, d_jobs, im, tab, fl);
-    hipLaunchKernelGGL((decode_wave_kernel<W, 3>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
+    // `lb`: stream bytes per lane, i.e. the chunk size the plan counted the tables' rows in (sqoa_dp_chunks): 12 -- the per-chunk costs
+    // spread over 1.5 x the bytes, as in the batch shape -- for plans without a QOI-compat stream among these (the speculative pass of
+    // sqoa_decode_qoi.hip reads the rows with 512-byte chunk numbers), else 8
+    auto run = [&](auto lb_tag) {
+        constexpr int LB = decltype(lb_tag)::value;
+        hipLaunchKernelGGL((decode_wave_kernel<W, 1, LB>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, 0u);
+        if (scans) hipLaunchKernelGGL(dp_scan_state, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, im, tab, fl);
+        hipLaunchKernelGGL((decode_wave_kernel<W, 2, LB>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
+        if (scans) hipLaunchKernelGGL(dp_scan_pixels, dim3(n_images), dim3(DP_SCAN_THREADS), 0, stream, d_jobs, im, tab, fl);
+        hipLaunchKernelGGL((decode_wave_kernel<W, 3, LB>), dim3(n_wgs), dim3(W * 64), 0, stream, d_jobs, nullptr, d_results, im, wg, tab, fl, per, fused);
+    };
+    if (lb == 12) run(std::integral_constant<int, 12>{});
+    else run(std::integral_constant<int, SQOA_DEC_LB>{});
     return hipGetLastError();
 }
 
@@ -1097,9 +1105,10 @@ extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const 
 // multi-pass streams of a plan -- how many chunks a workgroup of a pass takes: few (many workgroups) while the chip is not
 // full, more when it is (inside a workgroup the chunks are chained through LDS, and a short chain is mostly ramp-up: 1024
 // images at 16 chunks per workgroup 9.2 ms).  One table row per workgroup.
-extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size) {
+extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size, int lb) {
     const uint32_t area = src_size > 22u ? src_size - 22u : 0u;   // (the QOI-compat chunk area: one byte longer than the SQOA one -- no start byte)
-    return area ? (area + sqoa::DEC_CHUNK - 1) / sqoa::DEC_CHUNK : 1u;
+    const uint32_t chunk = 64u * (uint32_t)(lb == 12 ? 12 : SQOA_DEC_LB);
+    return area ? (area + chunk - 1) / chunk : 1u;
 }
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, unsigned wgs, size_t* row_bytes) {
     if (row_bytes) *row_bytes = sizeof(sqoa::dp_chunk);

@@ -22,7 +22,7 @@ extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
-extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size);
+extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size, int lb);
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, unsigned wgs, size_t* row_bytes);
 extern "C" size_t sqoa_dq_state_bytes(void);
 extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const int* d_ids, int n, void* d_word, hipStream_t stream);
@@ -117,7 +117,7 @@ struct sqoa_hip_plan {
     int shape = 0;                      // decode, the streams that get a workgroup each: the wave decoder's shape (sqoa_launch_decode_wave) -- bit 0 = many short
                                         // streams, bit 1 = 12 stream bytes per lane, bit 2 = position-major stores
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
-    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256};   // decode: the few large streams that take the three-pass route
+    sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256, 8};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
     sqoa_st_tables st = {nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};   // encode: the few large images cut into strips
     int n_cut_sqoa = 0, n_cut_qoi = 0;   // how many at the front of the SQOA / QOI-compat id list they are
@@ -497,13 +497,23 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         // stream 0.103 -> 0.091 ms: every workgroup of a pass pays a prologue and the ramp of its chains; the same number of chunks
         // as 8 x 1 Mpixel the same way: 0.103 -> 0.106 ms, hence one stream only).  Not where the speculative pass will read the
         // rows: its warm-up is one row, thrown away (0.26 -> 0.49 ms for that stream in QOI-compat).
+        // 768-byte chunks (12 stream bytes per lane) where no QOI-compat stream is among them -- the speculative pass reads the rows with
+        // 512-byte chunk numbers -- and the streams go to four channels (to three the wide shape loses: sqoa_launch_decode_wave);
+        // SQOA_HIP_DEC_WIDE=0 / 1 forces it where it may be forced
+        {
+            bool all4 = true;
+            for (int k = 0; k < n_multi_dec; ++k) if (jobs[ids_a[k]].desc.channels != 4) all4 = false;
+            int wide = all4;
+            if (const char* kw = getenv("SQOA_HIP_DEC_WIDE")) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
+            p->dp.lb = (wide && !p->dp.any_qoi) ? 12 : 8;
+        }
         unsigned long long total_chunks = 0;
-        for (int k = 0; k < n_multi_dec; ++k) total_chunks += sqoa_dp_chunks(jobs[ids_a[k]].src_size);
+        for (int k = 0; k < n_multi_dec; ++k) total_chunks += sqoa_dp_chunks(jobs[ids_a[k]].src_size, p->dp.lb);
         const uint32_t per = sqoa_dp_per_wg(total_chunks, !p->dp.any_qoi && n_multi_dec == 1 ? 1024u : 4096u, &dp_row_bytes);
         p->dp.per = per;
         for (int k = 0; k < n_multi_dec; ++k) {
             const int i = ids_a[k];
-            const uint32_t nc = sqoa_dp_chunks(jobs[i].src_size), nw = (nc + per - 1) / per;
+            const uint32_t nc = sqoa_dp_chunks(jobs[i].src_size, p->dp.lb), nw = (nc + per - 1) / per;
             if (dp_wgs.size() + nw > 0x7fffffffull) break;   // (the rest of the prefix gets a workgroup per stream: the launch splits the id list at dp.n_images)
             const uint32_t img = (uint32_t)dp_images.size();
             dp_images.push_back({i, (uint32_t)dp_rows, nc, nw});
