@@ -46,9 +46,17 @@ struct EncState {
 };
 
 // Wait until the 8-byte LDS word carries `tag` in its high half; returns the low half.
+// ASM: the hand-written poll of the decoder (chain_poll).  The SQOA-native encoder keeps the loop as the compiler makes it: it is short of
+// SGPRs, not of scalar issue slots -- with the poll its SGPR spills went from 79 to 97 and the kernel from 1.57 to 1.59 ms.  The QOI-compat
+// encoder takes it (round 4: headline batch 2.98 -> 2.90 ms, icons 2.94 -> 2.97 ms).
+template <bool ASM = false>
 SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& st) {
-#ifndef SQOA_ENC_ASM_POLL   // the loop as the compiler makes it: the encoder is short of SGPRs, not of scalar issue slots -- with the hand-written
-                           // poll of the decoder (chain_poll) its SGPR spills went from 79 to 97 and the kernel from 1.57 to 1.59 ms
+#ifdef SQOA_ENC_ASM_POLL
+    constexpr bool USE_ASM = true;
+#else
+    constexpr bool USE_ASM = ASM;
+#endif
+    if constexpr (!USE_ASM) {
     for (uint32_t spin = 0; spin < SPIN_MAX; ++spin) {
         unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t hi = bcast_first((uint32_t)(v >> 32));
@@ -57,12 +65,13 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
     }
     st.bad = 1;
     return 0;
-#else
+    } else {
     uint32_t val;
-    const uint32_t t = chain_poll<SQOA_ENC_SPIN_SLEEP>(slot, tag, 0xffffffffu, val);   // (no tag is ever 2^32 - 1: sub-tile numbers + 1)
+    const uint32_t t = st.eager ? chain_poll<1>(slot, tag, 0xffffffffu, val)                       // (a strip job: EncState)
+                                : chain_poll<SQOA_ENC_SPIN_SLEEP>(slot, tag, 0xffffffffu, val);   // (no tag is ever 2^32 - 1: sub-tile numbers + 1)
     if (t != tag) { st.bad = 1; return 0; }
     return val;
-#endif
+    }
 }
 
 SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
@@ -829,7 +838,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         unsigned long long* my_run = &s_run[(j / W) & 1][w];
         if (!all_eq && !last_sub) chain_post(my_run, j + 1, trail, lane);
         uint32_t c_in = 0;
-        if (j > 0 && (E[0] & 1ull)) c_in = chain_wait(&s_run[((j - 1) / W) & 1][(j - 1) % W], j, st);
+        if (j > 0 && (E[0] & 1ull)) c_in = chain_wait<QOI>(&s_run[((j - 1) / W) & 1][(j - 1) % W], j, st);
         if (all_eq && !last_sub) chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
 
         // ---- QOI: colour index entering this sub-tile, and the one leaving it ---------
@@ -988,7 +997,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
         PHASE(4);
         // ---- output position from the chain, then drain the staging buffer -------------
-        const uint32_t pos = j == 0 ? hdr_len : chain_wait(&s_pos[(j - 1) % W], j, st);
+        const uint32_t pos = j == 0 ? hdr_len : chain_wait<QOI>(&s_pos[(j - 1) % W], j, st);
         PHASE(5);
         if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
         flush_stage(stage, sbase, dst + pos, lane);
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             // multiple of 62 -- floor((c_in + 512) / 62) - floor(c_in / 62) of them, 8 or 9 --, and behind the last pixel the flush
             // of the remainder (seqoia.h:554-561) if the run ends here.  Run pixels never touch the colour index (seqoia.h:544-550
             // come before :563): the table entering the sub-tile is the one leaving it.
-            const uint32_t c_in = chain_wait(prev_run, j, st);
+            const uint32_t c_in = chain_wait<QOI>(prev_run, j, st);
             chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
             const uint32_t kend = c_in + ENC_SUB, qend = kend / 62u;
             const uint32_t nfd = qend - c_in / 62u, r = kend - 62u * qend;
@@ -1063,7 +1072,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             sbase = nbytes;
             qoi_table_hop(j, false, [](unsigned long long*) {});
         } else if (flat) {
-            const uint32_t c_in = chain_wait(prev_run, j, st);
+            const uint32_t c_in = chain_wait<QOI>(prev_run, j, st);
             chain_post(my_run, j + 1, c_in + ENC_SUB, lane);
             // k runs over c_in+1 .. c_in+512: exactly one of them is a multiple of 512 (0xfd, seqoia.h:546-549); the
             // last pixel additionally owns the flush (seqoia.h:554-561)
@@ -1192,7 +1201,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             if (__ballot((e0 & 1u) != 0u) != 0ull) {
 #endif
                 // some lane starts inside a run: its leading repeats continue a run of `carry` pixels in front of the lane
-                const uint32_t c_in = (bcast_first(e0) & 1u) ? chain_wait(prev_run, j, st) : 0u;
+                const uint32_t c_in = (bcast_first(e0) & 1u) ? chain_wait<QOI>(prev_run, j, st) : 0u;
                 const uint32_t nE = ~E8;
                 const uint32_t f = (uint32_t)__builtin_ctz(nE);                                   // leading repeats, 0..8 (bit 8 of ~E8 is set)
                 // the sub-tile pixel index of the last pixel below my stretch that does NOT repeat: a running maximum over the lanes
@@ -1289,7 +1298,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         cur_pb = nxt_pb.value();
         cur_pa = nxt_pa.value();
         PHASE(4);
-        const uint32_t pos = chain_wait(&s_pos[(j - 1) % W], j, st);
+        const uint32_t pos = chain_wait<QOI>(&s_pos[(j - 1) % W], j, st);
         PHASE(5);
         chain_post(&s_pos[w], j + 1, pos + sbase, lane);
 #ifndef SQOA_DBG_NOFLUSH
