@@ -297,7 +297,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     constexpr uint32_t SWEEP_MIN_PX = SQOA_DEC_SWEEP_MIN;        // ... and must: a chunk of a few hundred pixels with a run or two in it is cheaper run by run
     constexpr uint32_t SWEEP_PX = 4096;                          // pixels a chunk may produce on this path (longer: runs of hundreds of pixels, the fill loop's home ground)
     __shared__ uint32_t s_swv[SWEEP ? W : 1][SWEEP ? DEC_R * 64 + 64 : 1];
-    __shared__ __attribute__((aligned(8))) uint32_t s_swb[SWEEP ? W : 1][SWEEP ? SWEEP_PX / 32 : 2];
+    __shared__ __attribute__((aligned(8))) uint2 s_swb[SWEEP ? W : 1][SWEEP ? SWEEP_PX / 32 : 1];   // .x: 32 start bits, .y: the starts in front of them
 
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
@@ -839,13 +839,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 // a popcount of the bit row, running base in an SGPR -- and every store instruction writes 64 consecutive pixels.
                 const uint32_t total = pos_in + ctot > N ? N - pos_in : ctot;
                 uint32_t* swv = s_swv[SWEEP ? w : 0];
-                uint32_t* swb = s_swb[SWEEP ? w : 0];
+                uint2* swb = s_swb[SWEEP ? w : 0];
                 // (the lane number, recomputed here and opaque to the compiler: with the kernel's `lane` everything below that depends
-                // on the lane alone -- the two mask words, LDS addresses -- is a loop invariant of the chunk loop, hoisted in front of
-                // it, and pays for its registers with spills of the walk's op records in the hot path: headline batch 3.12 -> 3.44 ms)
+                // on the lane alone -- mask words, LDS addresses -- is a loop invariant of the chunk loop, hoisted in front of it, and
+                // pays for its registers with spills of the walk's op records in the hot path: headline batch 3.12 -> 3.44 ms)
                 uint32_t lane;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-                swb[lane] = 0u; swb[lane + 64] = 0u;                                 // (4096 bits)
+                swb[lane] = uint2{0u, 0u}; swb[lane + 64] = uint2{0u, 0u};             // (4096 bits)
                 uint32_t nops = 0;
                 static_for<0, DEC_R>([&](auto i_tag) -> bool { constexpr int i = decltype(i_tag)::value; if ((uint32_t)i >= iters) return false; nops += sra31(0u - (meta[i] >> CL_BITS)) & 1u; return true; });
                 const uint32_t rank0 = wave_incl_scan(nops) - nops;                    // ops in the lanes below mine
@@ -860,46 +860,52 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                     const uint32_t on = sra31(0u - (m >> CL_BITS)) & sra31(start - total);
                     const uint32_t idx = ((rank0 + (uint32_t)i) & on) | (((uint32_t)(DEC_R * 64) + (uint32_t)lane) & ~on);
                     swv[idx] = v;
-                    __hip_atomic_fetch_or(&swb[(start >> 5) & (SWEEP_PX / 32 - 1) & on], (1u << (start & 31u)) & on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_or(&swb[(start >> 5) & (SWEEP_PX / 32 - 1) & on].x, (1u << (start & 31u)) & on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     return true;
                 });
-                uint32_t base = 0;                                                     // op starts in front of the 64 pixels at hand
-                if (oc == 4) {
-                    const uint32_t lm_lo = lane < 32 ? (2u << lane) - 1u : ~0u, lm_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;   // bits 0 .. lane
-                    gptr32 o = (gptr32)out + pos_in;
-                    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
-                        const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));   // (the same address in every lane)
-                        const uint32_t r = __builtin_popcount(bw.y & lm_hi) + __builtin_popcount(bw.x & lm_lo) + base;   // >= 1: the chunk's first op starts at its pixel 0
-                        const uint32_t v = swv[r - 1u];
-                        if (x0 + (uint32_t)lane < total) o[x0 + lane] = v;
-                        base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                // the starts in front of every 32-bit word of the row (an exclusive prefix sum of the words' popcounts: the second half
+                // of the row only when the chunk reaches it)
+                {
+                    const uint32_t c0 = (uint32_t)__builtin_popcount(swb[lane].x);
+                    const uint32_t s0 = wave_incl_scan(c0);
+                    swb[lane].y = s0 - c0;
+                    if (total > SWEEP_PX / 2) {
+                        const uint32_t c1 = (uint32_t)__builtin_popcount(swb[lane + 64].x);
+                        swb[lane + 64].y = bcast_lane(s0, 63) + wave_incl_scan(c1) - c1;
                     }
-                } else {
-                    // Three channels: the 64 pixels of a step are 192 bytes = 48 dwords (at whatever alignment 3 * pos_in has: unaligned
-                    // dword stores are fine), dword j = the bytes 4 j .. 4 j + 3 of the step = the tail of pixel pa = j + j / 3 and the
-                    // head of pixel pa + 1, i.e. the six bytes rgb(pa) rgb(pa + 1) shifted by j mod 3 bytes.
-                    const uint32_t pa = lane + ((lane * 171u) >> 9), ph = lane - 3u * ((lane * 171u) >> 9);   // (lane < 48 where it counts: pa <= 62)
-                    const uint32_t la_lo = pa < 32u ? (2u << pa) - 1u : ~0u, la_hi = pa < 32u ? 0u : (2u << (pa - 32u)) - 1u;   // bits 0 .. pa
-                    const uint32_t pb = pa + 1u;                                           // <= 63
-                    typedef uint32_t u32_una __attribute__((aligned(1)));
-                    typedef __attribute__((address_space(1))) u32_una* gptr32u;
-                    gptr8 ob = out + (size_t)pos_in * 3u;
-                    for (uint32_t x0 = 0; x0 < total; x0 += 64u) {
-                        const uint2 bw = *reinterpret_cast<const uint2*>(swb + (x0 >> 5));
-                        const uint32_t ra = __builtin_popcount(bw.y & la_hi) + __builtin_popcount(bw.x & la_lo) + base;
-                        const uint32_t rb = ra + (((pb < 32u ? bw.x : bw.y) >> (pb & 31u)) & 1u);
-                        const uint32_t va = swv[ra - 1u] & 0x00ffffffu, vb = swv[rb - 1u];
-                        const uint32_t d = __builtin_amdgcn_alignbyte((vb >> 8) & 0xffffu, va | vb << 24, ph);
-                        const uint32_t left = 3u * (total - x0);                           // bytes of the chunk from this step on
-                        const uint32_t b0 = 4u * lane;
-                        if (lane < 48u && b0 + 4u <= left) *(gptr32u)(ob + 3u * x0 + b0) = d;
-                        else if (lane < 48u && b0 < left) {                                // the chunk's last one to three bytes
-                            gptr8 q = ob + 3u * x0 + b0;
-                            q[0] = (uint8_t)d;
-                            if (b0 + 1u < left) q[1] = (uint8_t)(d >> 8);
-                            if (b0 + 2u < left) q[2] = (uint8_t)(d >> 16);
+                }
+                // The sweep: 256 pixels per step, FOUR consecutive ones per lane -- their ops are the number of starts at or below each:
+                // the prefix of the row word + a popcount inside it, then one bit test per pixel -- and one 16-byte (three channels:
+                // 12-byte) store per lane.
+                for (uint32_t x0 = 0; x0 < total; x0 += 256u) {
+                    const uint32_t x = x0 + 4u * lane, sh = x & 31u;
+                    const uint2 bw = swb[x >> 5];
+                    const uint32_t r0 = bw.y + (uint32_t)__builtin_popcount(bw.x & ((2u << sh) - 1u));   // >= 1 inside the chunk: its first op starts at its pixel 0
+                    const uint32_t b = bw.x >> sh;
+                    const uint32_t r1 = r0 + ((b >> 1) & 1u), r2 = r1 + ((b >> 2) & 1u), r3 = r2 + ((b >> 3) & 1u);
+                    const uint32_t v0 = swv[r0 - 1u], v1 = swv[r1 - 1u], v2 = swv[r2 - 1u], v3 = swv[r3 - 1u];
+                    if (oc == 4) {
+                        typedef u32x4 u32x4_una __attribute__((aligned(4)));
+                        typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
+                        gptr32 o = (gptr32)out + pos_in + x;
+                        if (x + 4u <= total) *(gptr128u)o = u32x4{v0, v1, v2, v3};
+                        else if (x < total) {                                              // the chunk's last one to three pixels
+                            o[0] = v0;
+                            if (x + 1u < total) o[1] = v1;
+                            if (x + 2u < total) o[2] = v2;
                         }
-                        base += (uint32_t)__builtin_popcount(bcast_first(bw.x)) + (uint32_t)__builtin_popcount(bcast_first(bw.y));
+                    } else {
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                        typedef u32x3 u32x3_una __attribute__((aligned(1)));
+                        typedef __attribute__((address_space(1))) u32x3_una* gptr96u;
+                        gptr8 o = out + ((size_t)pos_in + x) * 3u;
+                        if (x + 4u <= total)   // r g b r | g b r g | b r g b
+                            *(gptr96u)o = u32x3{(v0 & 0x00ffffffu) | v1 << 24, ((v1 >> 8) & 0xffffu) | v2 << 16, ((v2 >> 16) & 0xffu) | v3 << 8};
+                        else if (x < total) {
+                            put_pixel<3>(o, 0, v0);
+                            if (x + 1u < total) put_pixel<3>(o, 1, v1);
+                            if (x + 2u < total) put_pixel<3>(o, 2, v2);
+                        }
                     }
                 }
             } else {
