@@ -140,8 +140,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ __attribute__((aligned(16))) u32x4 s_qtab[257];
     // per op of the producer's chunk, in stream order: transform value bytes (later: the transform scanned over its segment,
     // later still: the op's pixel), and 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixel count << 9
-    __shared__ uint32_t s_recv[P][QK_CHUNK];
-    __shared__ uint16_t s_recm[P][QK_CHUNK];
+    // (one 8-byte record: the resolver -- the image's serial path -- takes a group's 64 records with one LDS instruction)
+    __shared__ uint2 s_rec[P][QK_CHUNK];
     __shared__ unsigned long long s_tab[64];       // the colour index (seqoia.h:712, :785-787): stamp << 32 | value
     __shared__ unsigned long long s_parse[2][P];
     __shared__ unsigned long long s_pos[P];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         uint32_t pxv = SPEC && c_begin ? bcast_first(rows[c_begin / dp_per].px_in) : kPxInit;
         [[maybe_unused]] unsigned long long rmask = 0;   // SPEC: index slots my own chunks read before writing them (per lane; OR-ed at the end)
 #ifdef SQOA_QTRACE  // diagnostic builds: where the resolver's time goes, written over the image's first pixels
-        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+        unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #define RPH(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
 #else
 #define RPH(k) do { } while (0)
@@ -261,8 +261,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!qk_wait<SQOA_QDEC_RSLEEP>(&s_ready[p], c + 1, info, bad)) break;
             RPH(1);
             const uint32_t T = info & 0xffffu;
-            uint32_t* recv = s_recv[p];
-            uint16_t* recm = s_recm[p];
+            uint2* rec = s_rec[p];
 #ifdef SQOA_DBG_Q_NOSERIAL
             if (false) {
 #else
@@ -271,43 +270,60 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 for (uint32_t gb = 0; gb < T; gb += 64) {
                     const uint32_t ng = T - gb < 64u ? T - gb : 64u;
                     const bool live = (uint32_t)lane < ng;
-                    const uint32_t m = live ? recm[gb + lane] : 0u;
-                    const uint32_t Sv = live ? recv[gb + lane] : 0u;
-                    const uint32_t nabs = (m & 4u) ? 0u : (m & 2u) ? 0xff000000u : 0xffffffffu;   // channels still relative to the segment's start
+                    // (a plain load: gb + lane < 512 always; lanes past the chunk's last op get an empty record word, their value is
+                    // never looked at)
+                    const uint2 r = rec[gb + lane];
+                    const uint32_t m = live ? r.y : 0u, Sv = r.x;
+                    uint32_t mN_, mA_;   // ~0: all four channels absolute / at least r g b
+                    asm("v_bfe_i32 %0, %1, 2, 1" : "=v"(mN_) : "v"(m));
+                    asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(mA_) : "v"(m));
+                    const uint32_t nabs = ~(mN_ | (mA_ & 0x00ffffffu));   // channels still relative to the segment's start
                     const bool isx = (m & 1u) != 0u;
                     const uint32_t slot = (m >> 3) & 63u;
-                    // the INDEX op at or below me that my segment starts at (none: it starts from the pixel entering the group)
                     const unsigned long long idxmask = __ballot(isx);
-                    const unsigned long long below = idxmask & (lt_mask | bit);
-                    const uint32_t head = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                    const uint32_t from_in = below ? 0u : ~0u;
-                    // All the group's INDEX ops at once, as a fixed point (seqoia.h:753-755 for each of them): an INDEX op's pixel
-                    // X is "the most recent earlier op whose pixel hashes to my slot, else the index as the groups before left
-                    // it"; the pixels of the ops behind it follow from X.  Start from the index, recompute until nothing
-                    // changes: every round settles at least the first INDEX op that was still wrong (the ops in front of it are
-                    // final), in practice one round finds nothing to change -- where one INDEX op after the other cost a
-                    // VALU -> SALU -> VALU round trip each.
+                    unsigned long long earl = 0, tab64 = 0;   // SPEC: the group-internal writers of an INDEX op's slot, as of the last round; the slot's entry
+                    uint32_t X = 0, val = 0, hv = 0;
                     RPH(2);
-                    const unsigned long long tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-                    const uint32_t tabv = (uint32_t)tab64;
-                    unsigned long long earl = 0;   // SPEC: the group-internal writers of an INDEX op's slot, as of the last round
-                    uint32_t X = tabv, val = 0, hv = 0;
-                    RPH(3);
-                    for (uint32_t round = 0; round <= ng; ++round) {
-                        const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(head << 2), (int)X);
-                        val = add8(((hx & ~from_in) | (hopen & from_in)) & nabs, Sv);
+                    if (idxmask == 0ull) {
+                        // No INDEX op in the group (two groups out of three on the headline batch): every pixel follows from the one the
+                        // open segment started at.  Nothing is read from LDS here -- not the index, not a ds_bpermute of segment heads
+                        // that do not exist: the image's serial path is this wave's dependent instructions, and every round trip to LDS
+                        // on it is a hundred-odd cycles (the writes further down are not waited for).
+                        val = add8(hopen & nabs, Sv);
                         hv = qoi_hash(val);
-                        if (idxmask == 0ull) break;                      // no INDEX op in the group: nothing to look up
-                        s_smask[lane] = 0ull;                            // per slot: the lanes whose pixel hashes to it
-                        if (live) __hip_atomic_fetch_or(&s_smask[hv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const unsigned long long earlier = __hip_atomic_load(&s_smask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & lt_mask;
-                        const uint32_t last = earlier ? 63u - (uint32_t)__builtin_clzll(earlier) : 0u;
-                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)val);
-                        const uint32_t Xn = earlier ? got : tabv;
-                        const bool changed = isx && Xn != X;
-                        X = Xn;
-                        earl = earlier;
-                        if (__ballot(changed) == 0ull) break;
+                    } else {
+                        // the INDEX op at or below me that my segment starts at (none: it starts from the pixel entering the group)
+                        const unsigned long long below = idxmask & (lt_mask | bit);
+                        const uint32_t head = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                        const uint32_t from_in = below ? 0u : ~0u;
+                        // All the group's INDEX ops at once, as a fixed point (seqoia.h:753-755 for each of them): an INDEX op's pixel
+                        // X is "the most recent earlier op whose pixel hashes to my slot, else the index as the groups before left
+                        // it"; the pixels of the ops behind it follow from X.  Start from the index, recompute until nothing
+                        // changes: every round settles at least the first INDEX op that was still wrong (the ops in front of it are
+                        // final), in practice one round finds nothing to change -- where one INDEX op after the other cost a
+                        // VALU -> SALU -> VALU round trip each.
+                        tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                        const uint32_t tabv = (uint32_t)tab64;
+                        X = tabv;
+                        RPH(3);
+                        for (uint32_t round = 0; round <= ng; ++round) {
+                            const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(head << 2), (int)X);
+                            val = add8(((hx & ~from_in) | (hopen & from_in)) & nabs, Sv);
+                            hv = qoi_hash(val);
+                            s_smask[lane] = 0ull;                            // per slot: the lanes whose pixel hashes to it
+                            if (live) __hip_atomic_fetch_or(&s_smask[hv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned long long earlier = __hip_atomic_load(&s_smask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & lt_mask;
+#ifdef SQOA_QDEC_SKIP_BPERM   // A/B builds
+                            if (__ballot(isx && earlier != 0ull) == 0ull) { earl = 0ull; if (__ballot(isx && X != tabv) == 0ull) break; }
+#endif
+                            const uint32_t last = earlier ? 63u - (uint32_t)__builtin_clzll(earlier) : 0u;
+                            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)val);
+                            const uint32_t Xn = earlier ? got : tabv;
+                            const bool changed = isx && Xn != X;
+                            X = Xn;
+                            earl = earlier;
+                            if (__ballot(changed) == 0ull) break;
+                        }
                     }
                     if constexpr (SPEC) {
                         // an INDEX op of my OWN chunks that took its pixel from an index entry nothing of my own chunks has written yet:
@@ -321,8 +337,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     if (live) {
                         __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                        recv[gb + lane] = val;   // for the producer's stores
+                        rec[gb + lane].x = val;   // for the producer's stores
                     }
+#ifdef SQOA_QTRACE   // (6: index update and hand-back; 8 / 9: groups / groups with INDEX ops)
+                    RPH(6); ph[8] += 1; ph[9] += idxmask ? 1 : 0;
+#endif
                 }
             }
             RPH(5);
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
 #ifdef SQOA_QTRACE
-        if (lane == 0) { unsigned long long* tr = (unsigned long long*)job.dst; for (int k = 0; k < 8; ++k) tr[k] = ph[k]; tr[6] = nchunks; }
+        if (lane == 0) { unsigned long long* tr = (unsigned long long*)job.dst; ph[10] = nchunks; for (int k = 0; k < 12; ++k) tr[k] = ph[k]; }
 #endif
         if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
         return;
@@ -352,8 +371,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // ================= the producers =======================================================================================
     const uint32_t p = (uint32_t)w - 1u;
     uint32_t* lds = s_bytes[p];
-    uint32_t* recv = s_recv[p];
-    uint16_t* recm = s_recm[p];
+    uint2* rec = s_rec[p];
     uint32_t stg[QK_NLD];
     auto load_chunk = [&](uint32_t c, uint32_t (&r)[QK_NLD]) {
         const uint32_t d0 = (p0 + c * QK_CHUNK) >> 2;
@@ -393,8 +411,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #endif
         for (uint32_t gb = 0; gb < held_T && P0 < N; gb += 64) {
             const bool live = gb + (uint32_t)lane < held_T;
-            const uint32_t cnt = live ? (uint32_t)recm[gb + lane] >> 9 : 0u;
-            const uint32_t v = live ? recv[gb + lane] : 0u;
+            const uint2 r = live ? rec[gb + lane] : uint2{0u, 0u};
+            const uint32_t cnt = r.y >> 9, v = r.x;
             const uint32_t pinc = wave_incl_scan(cnt);
             const uint32_t Pp = P0 + pinc - cnt;
             const uint32_t gtot = bcast_lane(pinc, 63);
@@ -564,10 +582,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t ab = (m & 4u) ? 0xffffffffu : (m & 2u) ? 0x00ffffffu : 0u;
             const uint32_t sv = add8(E.v & open & ~ab, rv[i]);
             const uint32_t sa = (E.abs & open) | ab;
-            if (m >> 9) {
-                recv[obase + i] = sv;
-                recm[obase + i] = (uint16_t)((m & ~6u) | ((sa >> 22) & 6u));
-            }
+            if (m >> 9) rec[obase + i] = uint2{sv, (m & ~6u) | ((sa >> 22) & 6u)};
         }
 
         // ---- pixel position: a plain sum, handed on at once ----
