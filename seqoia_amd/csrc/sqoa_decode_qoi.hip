@@ -249,27 +249,42 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #else
 #define RPH(k) do { } while (0)
 #endif
+        uint32_t rp = c_begin % (uint32_t)P;
         for (uint32_t c = c_begin; c < c_end; ++c) {
             if (SPEC && c == chunk_first) {   // the state my own chunks start from: exact (chunk 0) or what the warm-up arrived at
                 my_dq[0].px = pxv;
                 my_dq[0].tab[lane] = (uint32_t)__hip_atomic_load(&s_tab[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             uint32_t hopen = pxv;   // the pixel the segment that is open at a group's first op started from: the one entering the chunk, or an INDEX op's
-            const uint32_t p = c % (uint32_t)P;
+            const uint32_t p = rp;   // c mod P
+            rp = rp + 1u == (uint32_t)P ? 0u : rp + 1u;
             uint32_t info = 0;
+            uint2* rec = s_rec[p];
             RPH(0);
             if (!qk_wait<SQOA_QDEC_RSLEEP>(&s_ready[p], c + 1, info, bad)) break;
             RPH(1);
             const uint32_t T = info & 0xffffu;
-            uint2* rec = s_rec[p];
 #ifdef SQOA_DBG_Q_NOSERIAL
             if (false) {
 #else
             if (!(info >> 31)) {
 #endif
+                uint32_t vlast = 0;   // the pixels of the group before: the chunk ends with its last op's
                 for (uint32_t gb = 0; gb < T; gb += 64) {
                     const uint32_t ng = T - gb < 64u ? T - gb : 64u;
                     const bool live = (uint32_t)lane < ng;
+                    // seqoia.h:785-787 for the whole group: the last writer of a slot wins; and the pixels, for the producer's stores
+                    auto commit = [&](uint32_t val, uint32_t hv) {
+                        if (live) {
+                            __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            rec[gb + lane].x = val;
+                        }
+                        vlast = val;
+#ifdef SQOA_QTRACE   // (6: index update and hand-back; 8: groups)
+                        RPH(6); ph[8] += 1;
+#endif
+                    };
                     // (a plain load: gb + lane < 512 always; lanes past the chunk's last op get an empty record word, their value is
                     // never looked at)
                     const uint2 r = rec[gb + lane];
@@ -290,8 +305,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         // that do not exist: the image's serial path is this wave's dependent instructions, and every round trip to LDS
                         // on it is a hundred-odd cycles (the writes further down are not waited for).
                         val = add8(hopen & nabs, Sv);
-                        hv = qoi_hash(val);
-                    } else {
+                        RPH(4);
+                        commit(val, qoi_hash(val));
+                        continue;
+                    }
+                    {
                         // the INDEX op at or below me that my segment starts at (none: it starts from the pixel entering the group)
                         const unsigned long long below = idxmask & (lt_mask | bit);
                         const uint32_t head = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
@@ -313,9 +331,6 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             s_smask[lane] = 0ull;                            // per slot: the lanes whose pixel hashes to it
                             if (live) __hip_atomic_fetch_or(&s_smask[hv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const unsigned long long earlier = __hip_atomic_load(&s_smask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & lt_mask;
-#ifdef SQOA_QDEC_SKIP_BPERM   // A/B builds
-                            if (__ballot(isx && earlier != 0ull) == 0ull) { earl = 0ull; if (__ballot(isx && X != tabv) == 0ull) break; }
-#endif
                             const uint32_t last = earlier ? 63u - (uint32_t)__builtin_clzll(earlier) : 0u;
                             const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)val);
                             const uint32_t Xn = earlier ? got : tabv;
@@ -331,18 +346,13 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         if (c >= chunk_first && isx && earl == 0ull && (uint32_t)(tab64 >> 32) <= (chunk_first << 10)) rmask |= 1ull << slot;
                     }
                     RPH(4);
-                    pxv = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)(ng - 1u));
-                    if (idxmask) hopen = (uint32_t)__builtin_amdgcn_readlane((int)X, 63 - __builtin_clzll(idxmask));
-                    // seqoia.h:785-787 for the whole group: the last writer of a slot wins
-                    if (live) {
-                        __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        rec[gb + lane].x = val;   // for the producer's stores
-                    }
-#ifdef SQOA_QTRACE   // (6: index update and hand-back; 8 / 9: groups / groups with INDEX ops)
-                    RPH(6); ph[8] += 1; ph[9] += idxmask ? 1 : 0;
+                    hopen = (uint32_t)__builtin_amdgcn_readlane((int)X, 63 - __builtin_clzll(idxmask));
+#ifdef SQOA_QTRACE   // (9: groups with INDEX ops)
+                    ph[9] += 1;
 #endif
+                    commit(val, hv);
                 }
+                if (T) pxv = (uint32_t)__builtin_amdgcn_readlane((int)vlast, (int)((T - 1u) & 63u));
             }
             RPH(5);
             qk_post(&s_done[p], c + 1, pxv, lane);
