@@ -332,6 +332,9 @@ SQOA_DEV SwarGroup qoi_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uin
     return o;
 }
 
+#ifndef SQOA_ENC_Q_PIPE
+#define SQOA_ENC_Q_PIPE 1
+#endif
 // The index probe (seqoia.h:563-572) of one row of 64 consecutive pixels, lane = pixel, rows in order: a pixel's candidate is the
 // most recent earlier pixel of the row on its slot (per-slot lane masks in LDS), else the slot as the rows before left it.
 // Returns 0x80 | slot where the pixel hits, 0 where it misses or repeats its predecessor (`ne` false: run pixels do not probe).
@@ -1170,6 +1173,36 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     for (int r = 0; r < ENC_S; ++r)
                         if ((nebits >> r) & 1u) atomicMax(&last[qoi_hash(rowpx[r])], (unsigned long long)(r * 64 + lane + 1) << 32 | rowpx[r]);
                 });
+#if SQOA_ENC_Q_PIPE
+                // The eight rows' probes, software-pipelined by hand.  Row r + 1 can only look at the table after row r has written it, but
+                // LDS executes a wave's instructions in order: nothing has to be WAITED for between row r's writes and row r + 1's reads.
+                // What a row does wait for is its own lane-mask word (who else of the row is on my slot); the write of the table entry
+                // depends on that word alone, not on the candidate pixel the ds_bpermute fetches -- so row r's ds_bpermute travels with row
+                // r + 1's reads, and a row costs one round trip to LDS instead of two.
+                {
+                    uint32_t ph[ENC_S], pcand[ENC_S];
+                    unsigned long long pm[ENC_S];
+                    auto probe_a = [&](int r) {   // my slot's entry as the rows before left it; my bit into the slot's lane mask; the mask
+                        const uint32_t h = qoi_hash(rowpx[r]);
+                        ph[r] = h;
+                        pcand[r] = s_tabw[w][h];
+                        if ((nebits >> r) & 1u) __hip_atomic_fetch_or(&s_smask[w][h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        pm[r] = __hip_atomic_load(&s_smask[w][h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    };
+                    probe_a(0);
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const bool ne = (nebits >> r) & 1u;
+                        const unsigned long long m = pm[r], lower = m & (le_mask >> 1);
+                        const int from = lower ? 63 - __builtin_clzll(lower) : lane;
+                        const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)rowpx[r]);
+                        if (ne && (m & ~le_mask) == 0ull) { s_tabw[w][ph[r]] = rowpx[r]; s_smask[w][ph[r]] = 0; }  // last writer of the slot in this row
+                        if (r + 1 < ENC_S) probe_a(r + 1);
+                        const uint32_t cand = lower ? near : pcand[r];
+                        hit[r * 64 + lane] = (uint8_t)((ne && cand == rowpx[r]) ? 0x80u | ph[r] : 0u);
+                    }
+                }
+#else
 #pragma unroll
                 for (int r = 0; r < ENC_S; ++r)
 #ifdef SQOA_DBG_Q_NOPROBE   // timing experiments only (wrong output)
@@ -1182,6 +1215,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 }
 #else
                     hit[r * 64 + lane] = (uint8_t)qoi_probe_row(rowpx[r], (nebits >> r) & 1u, s_tabw[w], s_smask[w], lane, le_mask);
+#endif
 #endif
                 const uint2 hv = *reinterpret_cast<const uint2*>(hit + 8 * lane);
                 // QOI_OP_INDEX where the pixel hits: one byte, the slot (seqoia.h:566-568)

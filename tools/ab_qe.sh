@@ -1,0 +1,8 @@
+#!/bin/bash
+# tools/ab_qe.sh "v1 v2 ...": QOI-compat ENCODE A/B of variants/*.so: headline batch, icons 4096 x 512^2 RGB, photo RGB; two alternating rounds
+vs=$1
+for r in 1 2; do for v in $vs; do
+  SQOA_LIB=variants/$v.so timeout -k 10 120 python tools/time_encode.py --qoi 1 2>/dev/null || exit 1
+  SQOA_LIB=variants/$v.so timeout -k 10 120 python tools/time_encode.py --qoi 1 --images 4096 --size 512 --channels 3 --cls icon 2>/dev/null || exit 1
+done; done
+for v in $vs; do SQOA_LIB=variants/$v.so timeout -k 10 120 python tools/time_encode.py --qoi 1 --channels 3 --cls photo 2>/dev/null || exit 1; done
