@@ -10,11 +10,14 @@
 //     that start in its 8 bytes, the ops laid out in stream order as records (transform, INDEX slot, pixel count), and --
 //     between two INDEX ops -- the pixel values as one segmented scan of the transforms, all without knowing the pixel or the
 //     index the chunk starts from;
-//   * what is serial per image is the walk over the INDEX ops: per INDEX op one add, one hash, one compare of the 64 ops'
-//     hashes against the slot (__ballot) and one v_readlane -- "the most recent earlier op of this group whose pixel hashes
-//     to my slot" -- with the index itself as the fall-back.  ONE wave does that for every chunk of the image, back to back,
-//     at raised priority: the running pixel stays in a register, there is no hand-over from wave to wave per chunk (which
-//     cost a post, a poll and a wake-up on the image's critical path 5 000 times per Mpixel image);
+//   * what is serial per image is the resolution of the INDEX ops, 64 records at a time.  A group without one (two out of three
+//     on the headline batch) is an add, a hash and LDS writes nobody waits for; a group with INDEX ops settles all of them at once
+//     as a fixed point -- "my pixel is the one of the most recent earlier op of the group that hashes to my slot, else the index
+//     as the groups before left it" through per-slot lane masks in LDS and two ds_bpermute per round, one round as a rule.  ONE
+//     wave does that for every chunk of the image, back to back, at raised priority: the running pixel stays in a register, there
+//     is no hand-over from wave to wave per chunk (which cost a post, a poll and a wake-up on the image's critical path 5 000
+//     times per Mpixel image).  That wave's dependent instructions ARE the image's critical path: DESIGN.md 3.3 has what each
+//     kind of them costs;
 //   * the index lives in LDS, ONE copy per image, as 64 x {value, stamp}: "index[hash(px)] = px" for 64 ops at once is one
 //     ds_max_u64 of (stream-order stamp << 32 | value) per op -- the last writer of a slot wins exactly as the
 //     reference's in-order stores do;
