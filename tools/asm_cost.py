@@ -40,4 +40,5 @@ def main():
     print(f"lines {a}-{b}: VALU {valu} (fast {cnt.get('fast',0)}, slow {cnt.get('slow',0)}, fast-op-with-SGPR {cnt.get('slow_sgpr',0)}) cost {cost:.0f}; "
           f"SALU {cnt.get('salu',0)} branch {cnt.get('branch',0)} LDS {cnt.get('lds',0)} VMEM {cnt.get('vmem',0)} wait/nop {cnt.get('wait',0)}")
     for k, v in sorted(slow_ops.items(), key=lambda x: -x[1])[:25]: print(f"   {v:5d} {k}")
-main()
+if __name__ == "__main__":
+    main()
