@@ -17,6 +17,13 @@ SQOA_DEV Fn compose(Fn g, Fn f) {
     return Fn{__builtin_amdgcn_perm(g.hi, g.lo, f.lo), __builtin_amdgcn_perm(g.hi, g.lo, f.hi)};
 }
 SQOA_DEV uint32_t apply(Fn f, uint32_t st) { return (uint32_t)(((unsigned long long)f.hi << 32 | f.lo) >> (8u * st)) & 0xffu; }
+// The same as ONE v_perm_b32 (a function is eight state bytes, the state is the byte selector) instead of a 64-bit shift, for the
+// per-lane application in the decoders' hot loops; and what follows it there -- the offset of my first op start among my LB bytes from the
+// parser state in front of them: A, N -> 0, inside an op (D1..D4) -> its 1..4 remaining bytes, X (past the chunk area) -> LB -- as a
+// table of seven bytes in two registers instead of two range tests and three selects.
+SQOA_DEV uint32_t apply_perm(Fn f, uint32_t st) { return __builtin_amdgcn_perm(f.hi, f.lo, st) & 0xffu; }
+template <int LB>
+SQOA_DEV uint32_t first_op_offset(uint32_t lst) { return __builtin_amdgcn_perm((uint32_t)LB << 16 | 0x0403u, 0x02010000u, lst) & 0xffu; }
 
 template <int CTRL, int ROWMASK>
 SQOA_DEV Fn scan_step(Fn F) {

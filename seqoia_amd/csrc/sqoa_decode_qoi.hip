@@ -505,11 +505,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         uint32_t st_in = seed_st;   // (the stream's start: A; SPEC: what the scan of pass 1 found in front of the warm-up's first chunk)
         if (c > c_begin && !qk_wait(&s_parse[((c - 1) / P) & 1][(c - 1) % P], c, st_in, bad)) break;
         if (!g_const && !last_chunk) qk_post(my_parse, c + 1, apply(G, st_in), lane);
-        const uint32_t lst = apply(Fx, st_in);
+        const uint32_t lst = apply_perm(Fx, st_in);
 
         // ---- walk: my ops, in order (seqoia.h:740-775 with qoi_compat) ----
         QP(2);
-        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)QK_LB : 0u);
+        uint32_t pos = first_op_offset<QK_LB>(lst);
         // Between two INDEX ops pixel values do not depend on the index: every op's record is its pixel RELATIVE to the INDEX op
         // (or the chunk start) its segment begins at.  Inside the lane the ops' transforms are composed as they are decoded; what
         // the lanes below contribute comes from one segmented scan over the lanes' totals further down.

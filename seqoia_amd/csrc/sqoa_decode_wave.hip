@@ -577,7 +577,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(1);
 
         // ---- 2. walk: every lane decodes its own ops in order (<= 8 of them) --------------------
-        const uint32_t lst = apply(Fx, st_in);  // parser state in front of my first byte
+        const uint32_t lst = apply_perm(Fx, st_in);  // parser state in front of my first byte
         if constexpr (MODE == 2) {
             if (qoi_stream) {
                 // QOI-compat stream: only the chunk's pixel count is wanted here (seqoia.h:740-775 with qoi_compat: every op is one
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         }
         // first op start: inside an op -> skip its remaining bytes; an ALPHA byte at an op boundary after an
         // op belongs to that op (whoever owns the op has read it), so it is skipped too
-        uint32_t pos = lst >= 2u && lst <= 5u ? lst - 1u : (lst == ST_X ? (uint32_t)DEC_LB : 0u);
+        uint32_t pos = first_op_offset<DEC_LB>(lst);
         bool sfx_ok = lst != ST_N;  // may the byte at `pos` be an ALPHA suffix of the op before it?
         uint32_t val[DEC_R];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
         uint32_t meta[DEC_R];  // pixels before the op inside my lane (CL_BITS) | cnt (11) << CL_BITS
