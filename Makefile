@@ -11,7 +11,7 @@ BUILD := build
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 CFLAGS_HOST := -std=gnu99 -O2 -fPIC -Wall -Wextra
 
-KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_decode_wave.hip $(CSRC)/sqoa_decode_qoi.hip $(CSRC)/sqoa_strips.hip $(CSRC)/sqoa_runtime.hip
+KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_decode_wave.hip $(CSRC)/sqoa_decode_bal.hip $(CSRC)/sqoa_decode_qoi.hip $(CSRC)/sqoa_strips.hip $(CSRC)/sqoa_runtime.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNELS)) $(BUILD)/sqoa_host.o
 
 all: lib oracle tools

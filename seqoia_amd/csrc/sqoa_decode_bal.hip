@@ -1,0 +1,568 @@
+// sqoa_decode_bal.hip -- the BALANCED wave-parallel SQOA decoder for colour streams (gfx950): one workgroup per stream, the batch shape.
+//
+// Replaces the serial parse of the reference decoder (seqoia.h:722-806) like decode_wave_kernel (sqoa_decode_wave.hip), whose
+// chunks / parser-as-function-scan / transform monoid / LDS chains it keeps.  What changes is WHO decodes an op.  There a lane owns
+// 8 or 12 consecutive stream BYTES and walks the ops that start in them, and the walk runs as many iterations as the busiest lane has
+// ops: on the headline batch 5.4 iterations per 768-byte chunk for 3.6 ops per lane -- a third of the walk's lane slots (and of the
+// store loop's) execute nothing (LUMA-dense stretches set the count, RGBA-dense ones sit idle).  Here a lane owns consecutive OPS:
+//
+//   1. parse (as there): every byte's transition function over 8 parser states, composed per lane (16 bytes), one DPP scan across
+//      the lanes; the chunk's exit state usually does not depend on its entry state and is posted before that is known.
+//   2. starts: with the state in front of its first byte a lane applies its 16 functions once more, one v_perm_b32 each, and has the
+//      parser state in front of every byte; "an op starts here" is a SWAR test on (state, next state), the 16 flags are gathered into
+//      a bit mask by v_dot4_u32_u8, counted, prefix-summed over the wave (the op's RANK in the chunk) and each start's byte offset
+//      goes to a list in LDS at its rank.
+//   3. walk: the chunk's n ops are dealt out q = ceil(n / 64) consecutive ones per lane -- lane j starts at list[j q] -- and every
+//      lane decodes its q ops (table look-ups and mask arithmetic as in decode_wave_kernel): q iterations whatever the content, all
+//      lanes busy but the tail.  Chunks of more than 512 ops (never from the encoder at 3 bytes per op: crafted streams) go in pieces.
+//   4. scans, chain, stores: as there.
+//
+// Because ownership no longer follows the bytes, the per-op records (8 slots) bound the OPS per piece, not the bytes per lane: the
+// chunk is 1024 bytes (16 per lane), and what a chunk costs whatever its size -- scans, chain hops, scalar control -- is spread
+// over a third more bytes than at 768.
+//
+// A RUN right behind an op repeats the pixel that op produces and is taken in the same walk iteration (pixel pairs, flat stretches);
+// that is part of the PARSER here (state G: "a RUN has just been taken along"), so that ranks count iterations.  The one thing the
+// parser cannot see without looking ahead is an ALPHA suffix behind such a RUN (seqoia.h:777-783 makes it part of the RUN, which then
+// is an op of its own): the encoder never writes one (a RUN is followed by the op of a pixel that differs); a stream that holds one
+// makes the parser leave through the absorbing state X and is handed to the exact decoder, like a stream with SQOA_OP_REF.
+#include <type_traits>
+
+#include "sqoa_decode_parts.h"
+
+#ifndef SQOA_PRIO_T1  // progress (in 64ths of the image) at which a workgroup drops to wave priority 2, 1, 0
+#define SQOA_PRIO_T1 40
+#define SQOA_PRIO_T2 54
+#define SQOA_PRIO_T3 61
+#endif
+#ifndef SQOA_BAL_LB
+#define SQOA_BAL_LB 16
+#endif
+#ifndef SQOA_BAL_SPIN_SLEEP
+#define SQOA_BAL_SPIN_SLEEP 4
+#endif
+
+namespace sqoa {
+namespace bal {
+
+// Parser states.  A: op boundary behind an op (an ALPHA suffix belongs to that op, a RUN is taken along with it); N: op boundary behind
+// an ALPHA suffix (another 0x60..0x7f byte is a run op of its own, seqoia.h:773-775; a RUN is taken along); G: op boundary behind a
+// RUN that was taken along (the next RUN starts an iteration of its own; an ALPHA byte: see the file comment) -- also the stream
+// start (no op to belong to); X: past the chunk area, or given up; D1..D4: inside an op, that many bytes to go.
+// The three entries of a byte's function that depend on the byte are the low three of its low half; the high half is a constant.
+enum : uint32_t { S_A = 0, S_N = 1, S_G = 2, S_X = 3, S_D1 = 4, S_D2 = 5, S_D3 = 6, S_D4 = 7 };
+constexpr uint32_t F_HI = 0x06050400u;                      // D1 -> A, D2 -> D1, D3 -> D2, D4 -> D3
+constexpr uint32_t F_DEAD = 0x03030303u;                    // a byte past the chunk area: no op starts there (seqoia.h:726)
+constexpr uint32_t DEC_ABORT_TAG = 0xffffffffu;
+
+template <int SLEEP>
+SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t& val) {
+    const uint32_t t = chain_poll<SLEEP>(slot, tag, DEC_ABORT_TAG, val);
+    return t == tag ? 0u : t == DEC_ABORT_TAG ? 1u : 2u;
+}
+SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
+    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int I, int N, class F>
+SQOA_DEV void static_for(F&& f) {
+    if constexpr (I < N) {
+        if (f(std::integral_constant<int, I>{})) static_for<I + 1, N>(f);
+    }
+}
+template <int CTRL, int ROWMASK>
+SQOA_DEV Xf xf_scan_step(Xf T) {
+    Xf P;  // the transform of the lanes below, identity (all zero) where there is none
+    constexpr bool BC = ROWMASK == 0xf;
+    P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, BC);
+    P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, BC);
+    return xf_then(P, T);
+}
+SQOA_DEV Xf wave_xf_scan(Xf T) {
+    T = xf_scan_step<DPP_ROW_SHR + 1, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 2, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 4, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_SHR + 8, 0xf>(T);
+    T = xf_scan_step<DPP_ROW_BCAST15, 0xa>(T);
+    T = xf_scan_step<DPP_ROW_BCAST31, 0xc>(T);
+    return T;
+}
+
+template <int W, int LB>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_bal_kernel(const sqoa_hip_job* __restrict__ jobs,
+                                                                                                    const int* __restrict__ job_ids,
+                                                                                                    sqoa_hip_result* __restrict__ results) {
+    static_assert(LB == 16, "the start flags are gathered four words of four states at a time");
+    constexpr int CHUNK = LB * 64, LDS_DW = CHUNK / 4 + 8;       // stream bytes per chunk; staged dwords: chunk + 8 look-ahead bytes + 3 of misalignment, rounded
+    constexpr int R = 8;                                         // record slots per lane = ops per lane and piece
+    constexpr int SPIN = SQOA_BAL_SPIN_SLEEP;
+    constexpr int CL_BITS = 13;                                  // pixels in front of an op inside its lane: at most R - 1 ops of at most 1024 pixels
+    constexpr uint32_t CL_MASK = (1u << CL_BITS) - 1u;
+    static_assert((R - 1) * 1024 <= (int)CL_MASK, "record layout");
+    __shared__ __attribute__((aligned(16))) uint32_t s_bytes[W][LDS_DW];
+    __shared__ uint32_t s_ftab[256];   // byte -> low half of its transition function
+    // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask} (decode_wave_kernel's table)
+    //   info: len (3) | (len*8 - 4) (6) << 3 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
+    __shared__ __attribute__((aligned(16))) u32x4 s_optab[256];
+    __shared__ uint32_t s_sfx[256];    // byte -> ALPHA suffix: delta << 24 | 8 (shift) | 1 (length), else 0
+    __shared__ uint16_t s_list[W][64 * R];   // per wave: byte offset in the chunk of the op start of every rank
+    __shared__ unsigned long long s_parse[2][W];
+    __shared__ unsigned long long s_pos[W];
+    __shared__ unsigned long long s_px[W];
+    __shared__ uint32_t s_path;  // 1 = decoded here, 2 = refused / left to the other kernels
+
+    const int lane = lane_id();
+    const int w = (int)bcast_first(threadIdx.x >> 6);
+    const int jid = job_ids[blockIdx.x];
+    const sqoa_hip_job job = jobs[jid];
+    sqoa_hip_result* res = &results[jid];
+    gcptr8 src = (gcptr8)job.src;
+    gptr8 out = (gptr8)job.dst;
+    const uint32_t size = job.src_size;
+
+    if (threadIdx.x == 0) {
+        // header (seqoia.h:672-688): written to the result exactly as sqoa_decode fills *desc
+        const uint32_t magic = (uint32_t)src[0] << 24 | (uint32_t)src[1] << 16 | (uint32_t)src[2] << 8 | src[3];
+        const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+        const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+        const uint32_t hc = src[12], hs = src[13], q = src[14] != 0x31;
+        res->len = 0; res->status = SQOA_HIP_ST_OK;   // the row as every launch must find it: nobody else has touched it yet (sqoa_runtime.hip, plan_enqueue)
+        res->desc.width = hw; res->desc.height = hh; res->desc.channels = (uint8_t)hc;
+        res->desc.colorspace = (uint8_t)hs; res->desc.qoi_compat = (uint8_t)q;
+        const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
+                          (magic == 0x716f6966u && !q) || hh >= 400000000u / hw);
+        uint32_t path = 1;
+        // a caller that states the shape it expects (non-zero job.desc.width / height) gets BADARG for any other header
+        const bool shape_ok = (job.desc.width == 0 || job.desc.width == hw) && (job.desc.height == 0 || job.desc.height == hh);
+        if (!ok || !shape_ok) { res->status = SQOA_HIP_ST_BADARG; path = 2; }
+        else {
+            const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
+            if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
+            else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }   // mono, QOI-compat, 1 / 2 channels out: the kernels behind
+        }
+        s_path = path;
+    }
+    if (lane == 0) { s_parse[0][w] = 0; s_parse[1][w] = 0; s_pos[w] = 0; s_px[w] = 0; }
+    for (uint32_t b0 = threadIdx.x; b0 < 256u; b0 += W * 64) {
+        const bool is_abs = b0 >= 0xfeu, is_luma = (b0 & 0xc0u) == 0x80u, is_run = (b0 - 0xc0u) < 0x3eu, is_sfx = (b0 - 0x60u) < 0x20u;
+        const uint32_t len = is_abs ? b0 - 0xfau : (is_luma ? 2u : 1u);
+        // transition function (low half; states A, N, G, X): see the enum
+        const uint32_t opn = len == 1u ? (uint32_t)S_A : (uint32_t)S_D1 + len - 2u;
+        const uint32_t fA = is_sfx ? (uint32_t)S_N : is_run ? (uint32_t)S_G : opn;
+        const uint32_t fN = is_run ? (uint32_t)S_G : opn;
+        const uint32_t fG = is_sfx ? (uint32_t)S_X : opn;
+        s_ftab[b0] = fA | fN << 8 | fG << 16 | (uint32_t)S_X << 24;
+        // op decode of seqoia.h:740-775 as a table
+        const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
+        const uint32_t vg = (b0 & 0x3fu) - 32u;
+        u32x4 e;
+        e.x = len | (len * 8u - 4u) << 3 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
+        e.y = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
+        e.z = is_luma ? (((vg - 8u) & 0xffu) | ((vg - 8u) & 0xffu) << 16) : 0u;
+        e.w = is_luma ? ((vg & 0xffu) << 8 | 0x000f000fu) : 0u;
+        s_optab[b0] = e;
+        s_sfx[b0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 9u) : 0u;
+    }
+    __syncthreads();
+    if (s_path != 1) return;
+
+    const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
+    const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
+    const uint32_t hc = src[12];
+    const uint32_t N = bcast_first(hw * hh);
+    const int oc = (int)bcast_first(job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u));
+    // Streams packed back to back (sqoa_hip_pack) start at any byte address: all stream offsets below are relative to the
+    // dword-aligned address at or in front of the stream; the `soff` bytes in front of it are loaded but never looked at.
+    const bool dw_out = (job.dst & 3ull) == 0;  // 4-channel pixels can be stored as dwords
+    const uint32_t soff = (uint32_t)(job.src & 3ull);
+    gcptr8 srca = src - soff;
+    const uint32_t size_a = size + soff;
+    const uint32_t p0 = kHeader + 1u + soff;    // first chunk byte (after the start byte, seqoia.h:705)
+    const uint32_t chunks_len = size_a - 8;     // seqoia.h:721
+    const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
+    const uint32_t nchunks = area ? (area + CHUNK - 1) / CHUNK : 1;
+    uint32_t bad = 0;
+
+#ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+    const unsigned long long tr_start = wall_clock64();
+#define BPHASE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ph[k] += t_ - ph_t; ph_t = t_; } while (0)
+#elif defined(SQOA_ASM_MARK)
+#define BPHASE(k) asm volatile("; SQOA_PHASE " #k)
+#else
+#define BPHASE(k) do { } while (0)
+#endif
+    uint32_t* lds = s_bytes[w];
+    uint16_t* list = s_list[w];
+    typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+    typedef const __attribute__((address_space(1))) u32x4_a4* gcptr128u;
+    u32x4 stg4 = {0u, 0u, 0u, 0u};
+    uint32_t stg1 = 0;
+    // the chunk's CHUNK + 32 bytes from its dword-aligned start: one 16-byte load per lane and eight dwords; straight-line when the
+    // whole window lies inside the stream (all but the last chunks)
+    // (the lane number recomputed where it is used, opaque to the compiler: everything derived from the kernel's `lane` alone is a loop
+    // invariant that is hoisted out of the chunk loop, kept in a register -- or spilled, and then reloaded in front of the loads with
+    // an s_waitcnt vmcnt(0) that waits for the stores of the chunk before)
+    auto fresh_lane = [&]() { uint32_t l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
+    auto load_chunk = [&](uint32_t c) {
+        const uint32_t lane = fresh_lane();
+        const uint32_t gs = p0 + c * CHUNK;
+        const uint32_t d0 = gs >> 2;
+        if ((d0 + LDS_DW) * 4u <= size_a) {
+            gcptr32 p = (gcptr32)srca + d0;
+            stg4 = ((gcptr128u)p)[lane];
+            stg1 = p[256 + (lane & 7)];
+        } else {
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const uint32_t d = d0 + 4u * lane + k; r[k] = d * 4u < size_a ? ((gcptr32)srca)[d] : 0u; }
+            stg4 = u32x4{r[0], r[1], r[2], r[3]};
+            const uint32_t d = d0 + 256u + (lane & 7);
+            stg1 = d * 4u < size_a ? ((gcptr32)srca)[d] : 0u;
+        }
+    };
+    auto stage = [&]() {
+        const uint32_t lane = fresh_lane();
+        *reinterpret_cast<u32x4*>(lds + 4 * lane) = stg4;
+        if (lane < LDS_DW - 256) lds[256 + lane] = stg1;
+    };
+
+    // One chunk.  IN (compile time) = interior chunk: every byte lies inside the chunk area and a successor exists.
+    auto body = [&](auto in_tag, uint32_t c) -> uint32_t {   // 1: go on with the wave's next chunk, 0: the image is done with here
+        constexpr bool IN = decltype(in_tag)::value;
+        BPHASE(7);
+        const bool more = c + W < nchunks;
+        if (more) load_chunk(c + W);
+        const uint32_t gs = p0 + c * CHUNK;               // stream offset of chunk byte 0
+        const bool last_chunk = IN ? false : c == nchunks - 1;
+        const uint32_t my0 = gs + LB * lane;
+        const uint32_t nlive = IN ? (uint32_t)LB : my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)LB ? (uint32_t)LB : chunks_len - my0);
+        const uint32_t live_end = IN ? (uint32_t)CHUNK : (chunks_len - gs > (uint32_t)CHUNK ? (uint32_t)CHUNK : chunks_len - gs);   // chunk bytes inside the area
+
+        // ---- 1. parse: each lane composes the transition functions of its 16 bytes, one wave scan ----
+        uint32_t qd[LB / 4];
+        {   // my 16 bytes start (gs & 3) bytes into dword 4 * lane of the wave's buffer: one 16-byte read, one dword, four v_alignbyte_b32
+            const u32x4 a = *reinterpret_cast<const u32x4*>(lds + 4 * lane);
+            const uint32_t dw[LB / 4 + 1] = {a.x, a.y, a.z, a.w, lds[4 * lane + 4]};
+#pragma unroll
+            for (int k = 0; k < LB / 4; ++k) qd[k] = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], gs & 3u);
+        }
+        Fn F{ID_LO, ID_HI};
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+            const uint32_t b = (qd[k / 4] >> (8 * (k & 3))) & 0xffu;
+            const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : F_DEAD;
+            F = compose(Fn{flo, F_HI}, F);
+        }
+        const Fn Fi = wave_compose_scan(F);
+        const Fn G{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)};
+        const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
+        // exit state independent of the entry state?  (every state but X, which enters no chunk of a stream still decoded here)
+        const uint32_t g0 = G.lo & 0xffu;
+        const bool g_const = (G.lo & 0x00ffffffu) == g0 * 0x010101u && G.hi == g0 * 0x01010101u;
+        unsigned long long* my_parse = &s_parse[(c / W) & 1][w];
+        BPHASE(0);
+        uint32_t st_in = S_G;    // stream start: no op in front (seqoia.h:773-775)
+        {
+            // An exit state that does not depend on the entry state is posted before the entry state is known; the two-deep slots are safe
+            // because the pixel chain below holds a wave back (it cannot finish chunk c + W before chunk c + 1 has been entered).
+            if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
+            if (c > 0) {
+                const uint32_t rc = chain_wait_rc<SPIN>(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in);
+                if (rc) { bad |= rc >> 1; return 0u; }
+            }
+            if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
+        }
+        BPHASE(1);
+
+        // ---- 2. starts: the parser state in front of every byte of mine, the op starts among them, their ranks, the list ----
+        const uint32_t lst = apply_perm(Fx, st_in);
+        // (my 16 bytes, opaque to the compiler from here on: it would otherwise keep the parse's 16 table addresses in registers across the
+        // scan and the chain wait -- and spill the walk's op records for them; recomputing them is one instruction each)
+#pragma unroll
+        for (int k = 0; k < LB / 4; ++k) asm volatile("" : "+v"(qd[k]));
+        uint32_t M;   // bit k: an op (a walk iteration) starts at my byte k
+        uint32_t trouble = 0;   // (last chunks only: X is where their dead bytes lead anyway)
+        {
+            uint32_t nxt[LB / 4];   // byte i of word w: the state BEHIND my byte 4 w + i
+            uint32_t st = lst;
+#pragma unroll
+            for (int wd = 0; wd < LB / 4; ++wd) {
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 4 * wd + i;
+                    const uint32_t b = (qd[wd] >> (8 * i)) & 0xffu;
+                    const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : F_DEAD;
+                    if (!IN) trouble |= ((st & 0xffu) == (uint32_t)S_G && flo == (1u | 0u << 8 | 3u << 16 | 3u << 24)) ? 1u : 0u;   // an ALPHA byte behind a RUN that was taken along
+                    st = __builtin_amdgcn_perm(F_HI, flo, st);   // (byte 0; the other bytes are states too, of no interest)
+                    o[i] = st;
+                }
+                const uint32_t p01 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0400u), p23 = __builtin_amdgcn_perm(o[3], o[2], 0x0c0c0400u);
+                nxt[wd] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+            }
+            // start at byte k  <=>  state in front of k is a boundary (A, N, G: <= 2) and the state behind it is A or inside an op
+            // (not N: the byte was an ALPHA suffix; not G: a RUN taken along; not X)
+            uint32_t fl[LB / 4];
+            uint32_t prev = lst << 24;
+#pragma unroll
+            for (int wd = 0; wd < LB / 4; ++wd) {
+                const uint32_t cur = __builtin_amdgcn_alignbyte(nxt[wd], prev, 3);
+                prev = nxt[wd];
+                const uint32_t t1 = cur + 0x05050505u, t2 = nxt[wd] + 0x04040404u, t3 = nxt[wd] + 0x07070707u;   // bit 3: cur >= 3; nxt >= 4; nxt != 0
+                fl[wd] = (~t1 & (t2 | ~t3)) & 0x08080808u;
+            }
+            const uint32_t m8lo = __builtin_amdgcn_udot4(fl[1], 0x80402010u, __builtin_amdgcn_udot4(fl[0], 0x08040201u, 0u, false), false);
+            const uint32_t m8hi = __builtin_amdgcn_udot4(fl[3], 0x80402010u, __builtin_amdgcn_udot4(fl[2], 0x08040201u, 0u, false), false);
+            M = (m8lo | m8hi << 8) >> 3;   // (the flags are 0x08 per byte)
+        }
+        const uint32_t n_lane = (uint32_t)__builtin_popcount(M);
+        const uint32_t rinc = wave_incl_scan(n_lane);
+        const uint32_t n_ops = bcast_lane(rinc, 63);
+        // (more than 64 R walk iterations in a chunk: two starts are two bytes apart or more on average unless one-byte ops that nothing takes
+        // along follow each other -- SQOA_OP_REF bytes, which hand the stream over anyway.  Checked, not assumed.)
+        if (n_ops > 64u * R) {   // (before the list is written: it has room for 64 R starts)
+            if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
+            return 0u;
+        }
+        {
+            // Every start's byte offset to the list at its rank.  Hand-written: per start the compiler's loop was a wave vote, two compares, a
+            // select and four scalar instructions around the five that do the work.  Here a lane that has run out of starts leaves EXEC
+            // (v_cmpx; it never comes back: its mask stays zero) and EXEC is put back once.  Eight steps: more starts in 16 bytes than that
+            // need one-byte ops that no predecessor takes along, which the encoder writes nowhere -- the loop behind is for streams that do.
+            const uint32_t rank0 = rinc - n_lane;
+            uint32_t m = M, t;
+            const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)list + 2u * rank0;
+            const uint32_t data0 = (uint32_t)(LB * lane);
+            const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+#define SQOA_BAL_LIST_STEP(OFF)                      \
+            "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"      \
+            "v_ffbl_b32_e32 %[t], %[m]\n\t"           \
+            "v_add_u32_e32 %[t], %[t], %[d0]\n\t"     \
+            "ds_write_b16 %[a], %[t] offset:" #OFF "\n\t" \
+            "v_add_u32_e32 %[t], -1, %[m]\n\t"        \
+            "v_and_b32_e32 %[m], %[t], %[m]\n\t"
+            asm volatile(
+                SQOA_BAL_LIST_STEP(0) SQOA_BAL_LIST_STEP(2) SQOA_BAL_LIST_STEP(4) SQOA_BAL_LIST_STEP(6)
+                SQOA_BAL_LIST_STEP(8) SQOA_BAL_LIST_STEP(10) SQOA_BAL_LIST_STEP(12) SQOA_BAL_LIST_STEP(14)
+                "s_mov_b64 exec, %[ex]\n\t"
+                "s_nop 4"      // (a VALU write of EXEC wants 5 wait states in front of a DPP instruction)
+                : [m] "+v"(m), [t] "=&v"(t) : [a] "v"(laddr), [d0] "v"(data0), [ex] "s"(exec_in) : "memory", "vcc");
+#undef SQOA_BAL_LIST_STEP
+            if (__ballot(m != 0u) != 0ull) {
+                uint16_t* my = list + rank0;
+                for (uint32_t i = 8; __ballot(m != 0u) != 0ull; ++i) {
+                    if (m != 0u) { my[i] = (uint16_t)(data0 + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // (the list is read by other lanes of this wave: LDS executes a wave's instructions in order)
+        }
+        // given up: SQOA_OP_REF is found by the walk; an ALPHA suffix behind a RUN that was taken along leaves the parser in X
+        if (IN ? (apply(G, st_in) == (uint32_t)S_X || st_in == (uint32_t)S_X) : (__ballot(trouble != 0u) != 0ull || st_in == (uint32_t)S_X)) {
+            if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
+            return 0u;
+        }
+        BPHASE(2);
+
+        // ---- 3. walk, scans, chain, stores: the chunk's ops in pieces of at most 64 R (one piece but for crafted streams) ----
+        const uint32_t cb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u);   // LDS byte address of chunk byte 0
+        const uint32_t optab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u32x4*)s_optab;
+        const uint32_t sfx_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_sfx;
+        auto window = [&](uint32_t a, uint32_t& lo, uint32_t& hi) {
+            lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+            const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+            lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
+            hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+        };
+        uint32_t pos_in = 0, px_in = kPxInit, pos_out, exit_v;
+        {
+            const uint32_t q = bcast_first((n_ops + 63u) >> 6);                                   // ops per lane
+            const uint32_t r_first = (uint32_t)lane * q;                                   // rank of my first op
+            const uint32_t mine = r_first >= n_ops ? 0u : (n_ops - r_first < q ? n_ops - r_first : q);
+            const uint16_t* my_starts = list + r_first;   // (the start of my i-th op: my_starts[i], read where i < mine)
+            uint32_t val[R];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
+            uint32_t meta[R];  // pixels before the op inside my lane (CL_BITS) | cnt (11) << CL_BITS
+            uint32_t amask[R]; // byte mask of the channels of val[] that are absolute
+            Xf T{0u, 0u};
+            uint32_t cl = 0, longest = 0, info_or = 0;
+            static_for<0, R>([&](auto i_tag) -> bool {
+                constexpr int i = decltype(i_tag)::value;
+                if ((uint32_t)i >= q) return false;
+                asm volatile("" : "=v"(val[i]), "=v"(amask[i]));   // (read later only where meta says the slot holds an op)
+                meta[i] = cl;                                      // no op in this slot of mine: zero pixels
+                if ((uint32_t)i < mine) {
+                    const uint32_t pos = my_starts[i];
+                    uint32_t lo, hi;
+                    window(cb_addr + pos, lo, hi);
+                    const u32x4 e = *(lcptr128)(uintptr_t)(optab_addr + (lo & 0xffu) * 16u);
+                    info_or |= e.x;
+                    const uint32_t len = e.x & 7u, setm = e.y;
+                    uint32_t cnt = (e.x >> 9) & 0x3ffu;
+                    // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op.  w1 = stream >> (8 * len - 4).
+                    const unsigned long long qq = (unsigned long long)hi << 32 | lo;
+                    const uint32_t w1 = (uint32_t)(qq >> ((e.x >> 3) & 63u));
+                    const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 >> 2) & 0x3fcu));
+                    const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
+                    [[maybe_unused]] const uint32_t adv = len + (se & 1u);
+                    // a RUN right behind the op (and its suffix) repeats the pixel this op produces: taken along, as the parser did (state G)
+                    const uint32_t w2 = w1 >> has8;
+                    uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
+                    if (!IN) extra &= sra31(pos + adv - live_end);                                         // (a RUN past the chunk area does not exist)
+                    cnt += extra;
+                    const uint32_t bse = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
+                    const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;                         // LUMA, seqoia.h:761-769
+                    const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
+                    T = xf_then(T, Xf{(d8 & ~setm) | (bse & setm), setm});
+                    val[i] = T.v;
+                    meta[i] = cl | cnt << CL_BITS;
+                    amask[i] = T.abs;
+                    cl += cnt;
+                    longest = longest > cnt ? longest : cnt;
+                }
+                return true;
+            });
+            if (__ballot(((info_or >> 20) & 1u) != 0u) != 0ull) {  // SQOA_OP_REF: serial path for the whole image
+                if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
+                return 0u;
+            }
+            if (more) stage();   // the walk was the last reader of this chunk's bytes
+            BPHASE(3);
+            // ---- wave scans: pixel positions and pixel transforms of the lanes below ------------
+            const uint32_t cinc = wave_incl_scan(cl);
+            const uint32_t ctot = bcast_lane(cinc, 63);
+            const Xf Ti = wave_xf_scan(T);
+            const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
+            const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
+            // ---- entry position / pixel from the chain, publish exits, store ------------------
+            {
+                if (c > 0) {
+                    // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
+                    // instructions in order), so it is there when the pixel word's tag is
+                    const uint32_t rc = chain_wait_rc<SPIN>(&s_px[(c - 1) % W], c, px_in);
+                    if (rc) { bad |= rc >> 1; return 0u; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    pos_in = bcast_first((uint32_t)__hip_atomic_load(&s_pos[(c - 1) % W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                }
+            }
+            BPHASE(4);
+            exit_v = xf_apply(Tg, px_in);
+            pos_out = pos_in + ctot > N ? N : pos_in + ctot;
+            if (!last_chunk && lane == 0) {
+                __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (pos_in < N) {
+                const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
+                const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
+                const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
+                if (plain) {  // the common piece: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
+                    // (hand-written as in decode_wave_kernel: the two predicates narrow EXEC directly, the stores take the image base from an
+                    // SGPR pair and a 32-bit byte offset, EXEC is put back once, to what it was on entry)
+                    const uint32_t lane_off = lane_p << 2;
+                    const unsigned long long obase = job.dst;
+                    const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+                    static_for<0, R>([&](auto i_tag) -> bool {
+                        constexpr int i = decltype(i_tag)::value;
+                        if ((uint32_t)i >= q) return false;
+                        const uint32_t m = meta[i], am = amask[i];
+                        const uint32_t v = add8(lane_px & ~am, val[i]);
+                        const uint32_t off = lane_off + ((m & CL_MASK) << 2);
+                        asm volatile(
+                            "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // cnt >= 1
+                            "global_store_dword %[off], %[v], %[base]\n\t"
+                            "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // cnt == 2: a literal op and the one-pixel run behind it
+                            "global_store_dword %[off], %[v], %[base] offset:4\n\t"
+                            "s_mov_b64 exec, %[ex]"
+                            :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [ex] "s"(exec_in), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+                        return true;
+                    });
+                    asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
+                } else {
+                    auto store_ops = [&](auto oc_tag) {
+                        constexpr int OC = decltype(oc_tag)::value;
+                        static_for<0, R>([&](auto i_tag) -> bool {
+                            constexpr int i = decltype(i_tag)::value;
+                            if ((uint32_t)i >= q) return false;
+                            const uint32_t m = meta[i];
+                            const uint32_t cnt = m >> CL_BITS;
+                            const uint32_t P = lane_p + (m & CL_MASK);
+                            const uint32_t am = amask[i];
+                            const uint32_t v = add8(lane_px & ~am, val[i]);
+                            if (cnt >= 1u && cnt <= 2u && P < N) put_pixel<OC>(out, P, v);
+                            if (cnt == 2u && P + 1u < N) put_pixel<OC>(out, P + 1u, v);
+                            unsigned long long runs = __ballot(cnt > 2u && P < N);
+                            while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
+                                const int l = __builtin_ctzll(runs);
+                                runs &= runs - 1ull;
+                                const uint32_t rp = bcast_lane(P, l), rv = bcast_lane(v, l);
+                                uint32_t rc = bcast_lane(cnt, l);
+                                if (rp + rc > N) rc = N - rp;
+                                fill_pixels<OC>(out, rp, rc, rv, lane);
+                            }
+                            return true;
+                        });
+                    };
+                    if (oc == 4 && dw_out) store_ops(std::integral_constant<int, 4>{});
+                    else if (oc == 4) store_ops(std::integral_constant<int, 40>{});
+                    else store_ops(std::integral_constant<int, 3>{});
+                }
+            }
+            BPHASE(5);
+        }
+        if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
+            if (pos_out < N) {
+                if (oc == 4 && dw_out) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                else if (oc == 4) fill_pixels<40>(out, pos_out, N - pos_out, exit_v, lane);
+                else fill_pixels<3>(out, pos_out, N - pos_out, exit_v, lane);
+            }
+            if (lane == 0) res->len = (int)(N * (uint32_t)oc);
+        }
+        return 1u;
+    };
+
+    uint32_t c = (uint32_t)w;
+    if (c < nchunks) { load_chunk(c); stage(); }
+    const uint32_t nint = area / CHUNK < nchunks - 1 ? area / CHUNK : nchunks - 1;  // fully live chunks that have a successor
+    uint32_t go = 1;
+    // Progress-based wave priority (see decode_wave_kernel): co-resident streams stay within a quarter of each other
+    const uint32_t thr1 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T1 >> 6), thr2 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T2 >> 6),
+                   thr3 = (uint32_t)((unsigned long long)nint * SQOA_PRIO_T3 >> 6);
+    uint32_t thr = thr1, pq = 0;
+    __builtin_amdgcn_s_setprio(3);
+    for (; go && c < nint; c += W) {
+        if (c >= thr) {
+            ++pq; thr = pq == 1 ? thr2 : pq == 2 ? thr3 : ~0u;
+            if (pq == 1) __builtin_amdgcn_s_setprio(2);
+            else if (pq == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        go = body(std::true_type{}, c);
+    }
+    for (; go && c < nchunks; c += W) go = body(std::false_type{}, c);
+    if (!go && lane == 0) {   // handed over, or the predecessor was: tell whoever waits on this wave
+        const unsigned long long gone = (unsigned long long)DEC_ABORT_TAG << 32;
+        __hip_atomic_store(&s_parse[0][w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_parse[1][w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_px[w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+#ifdef SQOA_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* tr = (unsigned long long*)((job.dst + job.dst_cap + 7) & ~7ull);
+        for (int k = 0; k < 8; ++k) tr[k] = ph[k];
+        tr[8] = tr_start; tr[9] = wall_clock64();
+        tr[10] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32;
+    }
+#endif
+}
+
+}  // namespace bal
+}  // namespace sqoa
+
+// One workgroup per stream, the balanced kernel (see the file comment): the plan's choice for plans of large streams that go to four
+// channels (sqoa_runtime.hip; SQOA_HIP_DEC_BAL = 0 / 1 forces it).
+extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((sqoa::bal::decode_bal_kernel<8, SQOA_BAL_LB>), dim3(n), dim3(8 * 64), 0, stream, d_jobs, d_ids, d_results);
+    return hipGetLastError();
+}

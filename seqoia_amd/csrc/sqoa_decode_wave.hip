@@ -1029,9 +1029,13 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 // channels: to three (byte stores, three per pixel) the stores are what the waves queue for, and twelve bytes per lane spread a
 // store instruction's 64 pixels over 1.5 x the cache lines -- photo 1024 x 1 Mpixel RGB 2.90 -> 3.16 ms (11 % FEWER instructions,
 // 24 % more issue-stall cycles: profiles/r04_a_photo_rgb_*).
+// `shape` bit 3: the BALANCED kernel (sqoa_decode_bal.hip: a lane owns consecutive ops, not consecutive bytes; 1024-byte chunks) -- the
+// plan's choice where it would pick the wide shape for large streams.
+extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape,
                                               sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+    if (shape & 8) return sqoa_launch_decode_bal(d_jobs, d_ids, n, d_results, stream);
 #ifndef SQOA_DEC_W
 #define SQOA_DEC_W 8
 #endif

@@ -446,6 +446,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             const size_t c0 = (size_t)n_multi;
             const char* kw = getenv("SQOA_HIP_DEC_WIDE");
             const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
+            const char* kb = getenv("SQOA_HIP_DEC_BAL");
             auto shape_of = [&](size_t a, size_t b) -> int {
                 if (a >= b) return 0;
                 unsigned long long by = 0, by4 = 0, px = 0;
@@ -461,7 +462,11 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 int wide = roomy && 4u * by4 >= 3u * by, sweep = shaped && roomy && by < px;
                 if (kw) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
                 if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
-                return p->small | wide << 1 | sweep << 2;
+                //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
+                //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
+                int bal = wide && !sweep && !p->small;
+                if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
+                return p->small | wide << 1 | sweep << 2 | bal << 3;
             };
             p->shape = shape_of(c0, ids_a.size());
         }

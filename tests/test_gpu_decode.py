@@ -27,18 +27,21 @@ def orc():
     return po
 
 
-@pytest.fixture(params=[("0", "0", "0"), ("0", "1", "0"), ("0", "1", "1"), ("1", "0", "0"), ("1", "1", "0")],
-                ids=["chained", "chained-wide", "chained-wide-sweep", "threepass", "threepass-wide"])
+@pytest.fixture(params=[("0", "0", "0", "0"), ("0", "1", "0", "0"), ("0", "1", "1", "0"), ("0", "1", "0", "1"), ("1", "0", "0", "0"), ("1", "1", "0", "0")],
+                ids=["chained", "chained-wide", "chained-wide-sweep", "chained-balanced", "threepass", "threepass-wide"])
 def route(request, monkeypatch):
     """Every route of the SQOA wave decoder (the plan reads SQOA_HIP_MULTIPASS / SQOA_HIP_DEC_WIDE / SQOA_HIP_DEC_SWEEP when it is
     filled): one workgroup per stream with the chunks chained through LDS -- eight stream bytes per lane, or twelve (what the plan
     picks by itself when every stream goes to four channels; forced here for every channel count), or twelve with the position-major
-    store path for chunks full of runs (the plan's choice for streams of under a byte per pixel; forced here for everything) -- and
+    store path for chunks full of runs (the plan's choice for streams of under a byte per pixel; forced here for everything), or the
+    balanced kernel (sqoa_decode_bal.hip: sixteen bytes per lane in the parse, the ops dealt out evenly over the lanes; the plan's
+    choice for large streams to four channels, forced here for everything) -- and
     the three chip-wide passes the plan picks by itself for few large streams, their tables counted in 512-byte chunks or (plans
     without a QOI-compat stream among them, to four channels; forced here wherever no such stream is) in 768-byte ones."""
     monkeypatch.setenv("SQOA_HIP_MULTIPASS", request.param[0])
     monkeypatch.setenv("SQOA_HIP_DEC_WIDE", request.param[1])
     monkeypatch.setenv("SQOA_HIP_DEC_SWEEP", request.param[2])
+    monkeypatch.setenv("SQOA_HIP_DEC_BAL", request.param[3])
     return request.param[0]
 
 

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p variants build/v_$name
-for f in sqoa_encode sqoa_decode sqoa_decode_wave sqoa_decode_qoi sqoa_strips sqoa_runtime; do
+for f in sqoa_encode sqoa_decode sqoa_decode_wave sqoa_decode_bal sqoa_decode_qoi sqoa_strips sqoa_runtime; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $@ -c seqoia_amd/csrc/$f.hip -o build/v_$name/$f.o &
 done
 wait
