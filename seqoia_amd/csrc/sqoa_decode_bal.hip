@@ -104,7 +104,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     //   info: len (3) | (len*8 - 4) (6) << 3 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
     __shared__ __attribute__((aligned(16))) u32x4 s_optab[256];
     __shared__ uint32_t s_sfx[256];    // byte -> ALPHA suffix: delta << 24 | 8 (shift) | 1 (length), else 0
-    __shared__ uint16_t s_list[W][64 * R];   // per wave: byte offset in the chunk of the op start of every rank
+#ifndef SQOA_BAL_LIST32   // the list's entries as dwords: two lanes' ds_write_b16 into one dword collide (2.881 -> 2.868 ms)
+#define SQOA_BAL_LIST32 1
+#endif
+    typedef std::conditional_t<SQOA_BAL_LIST32 != 0, uint32_t, uint16_t> list_t;
+    __shared__ list_t s_list[W][64 * R + 2 * R];   // (+ room for the reads of the lanes behind the last start, and one entry in front)   // per wave: byte offset in the chunk of the op start of every rank
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #define BPHASE(k) do { } while (0)
 #endif
     uint32_t* lds = s_bytes[w];
-    uint16_t* list = s_list[w];
+    list_t* list = s_list[w] + R;
     typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
     typedef const __attribute__((address_space(1))) u32x4_a4* gcptr128u;
     u32x4 stg4 = {0u, 0u, 0u, 0u};
@@ -246,13 +250,24 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
             for (int k = 0; k < LB / 4; ++k) qd[k] = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], gs & 3u);
         }
-        Fn F{ID_LO, ID_HI};
+        // (the 16 table reads are issued together and waited for once -- the empty asm wants all of them in registers; left to itself
+        // the scheduler, at this kernel's register pressure, made it one LDS round trip per byte)
+        uint32_t flo[LB];
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             const uint32_t b = (qd[k / 4] >> (8 * (k & 3))) & 0xffu;
-            const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : F_DEAD;
-            F = compose(Fn{flo, F_HI}, F);
+            flo[k] = (uint32_t)k < nlive ? s_ftab[b] : F_DEAD;
         }
+#ifndef SQOA_BAL_PARSE_BATCH
+#define SQOA_BAL_PARSE_BATCH 1
+#endif
+#if SQOA_BAL_PARSE_BATCH
+        asm volatile("" : "+v"(flo[0]), "+v"(flo[1]), "+v"(flo[2]), "+v"(flo[3]), "+v"(flo[4]), "+v"(flo[5]), "+v"(flo[6]), "+v"(flo[7]));
+        asm volatile("" : "+v"(flo[8]), "+v"(flo[9]), "+v"(flo[10]), "+v"(flo[11]), "+v"(flo[12]), "+v"(flo[13]), "+v"(flo[14]), "+v"(flo[15]));
+#endif
+        Fn F{ID_LO, ID_HI};
+#pragma unroll
+        for (int k = 0; k < LB; ++k) F = compose(Fn{flo[k], F_HI}, F);
         const Fn Fi = wave_compose_scan(F);
         const Fn G{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)};
         const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
@@ -331,27 +346,37 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             // need one-byte ops that no predecessor takes along, which the encoder writes nowhere -- the loop behind is for streams that do.
             const uint32_t rank0 = rinc - n_lane;
             uint32_t m = M, t;
-            const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)list + 2u * rank0;
+            const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) list_t*)list + (uint32_t)sizeof(list_t) * rank0;
             const uint32_t data0 = (uint32_t)(LB * lane);
             const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+#if SQOA_BAL_LIST32
+#define SQOA_BAL_LIST_WR "ds_write_b32"
+#else
+#define SQOA_BAL_LIST_WR "ds_write_b16"
+#endif
 #define SQOA_BAL_LIST_STEP(OFF)                      \
             "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"      \
             "v_ffbl_b32_e32 %[t], %[m]\n\t"           \
             "v_add_u32_e32 %[t], %[t], %[d0]\n\t"     \
-            "ds_write_b16 %[a], %[t] offset:" #OFF "\n\t" \
+            SQOA_BAL_LIST_WR " %[a], %[t] offset:" #OFF "\n\t" \
             "v_add_u32_e32 %[t], -1, %[m]\n\t"        \
             "v_and_b32_e32 %[m], %[t], %[m]\n\t"
             asm volatile(
+#if SQOA_BAL_LIST32
+                SQOA_BAL_LIST_STEP(0) SQOA_BAL_LIST_STEP(4) SQOA_BAL_LIST_STEP(8) SQOA_BAL_LIST_STEP(12)
+                SQOA_BAL_LIST_STEP(16) SQOA_BAL_LIST_STEP(20) SQOA_BAL_LIST_STEP(24) SQOA_BAL_LIST_STEP(28)
+#else
                 SQOA_BAL_LIST_STEP(0) SQOA_BAL_LIST_STEP(2) SQOA_BAL_LIST_STEP(4) SQOA_BAL_LIST_STEP(6)
                 SQOA_BAL_LIST_STEP(8) SQOA_BAL_LIST_STEP(10) SQOA_BAL_LIST_STEP(12) SQOA_BAL_LIST_STEP(14)
+#endif
                 "s_mov_b64 exec, %[ex]\n\t"
                 "s_nop 4"      // (a VALU write of EXEC wants 5 wait states in front of a DPP instruction)
                 : [m] "+v"(m), [t] "=&v"(t) : [a] "v"(laddr), [d0] "v"(data0), [ex] "s"(exec_in) : "memory", "vcc");
 #undef SQOA_BAL_LIST_STEP
             if (__ballot(m != 0u) != 0ull) {
-                uint16_t* my = list + rank0;
+                list_t* my = list + rank0;
                 for (uint32_t i = 8; __ballot(m != 0u) != 0ull; ++i) {
-                    if (m != 0u) { my[i] = (uint16_t)(data0 + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
+                    if (m != 0u) { my[i] = (list_t)(data0 + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
                 }
             }
             __builtin_amdgcn_wave_barrier();   // (the list is read by other lanes of this wave: LDS executes a wave's instructions in order)
@@ -375,22 +400,33 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         };
         uint32_t pos_in = 0, px_in = kPxInit, pos_out, exit_v;
         {
-            const uint32_t q = bcast_first((n_ops + 63u) >> 6);                                   // ops per lane
-            const uint32_t r_first = (uint32_t)lane * q;                                   // rank of my first op
-            const uint32_t mine = r_first >= n_ops ? 0u : (n_ops - r_first < q ? n_ops - r_first : q);
-            const uint16_t* my_starts = list + r_first;   // (the start of my i-th op: my_starts[i], read where i < mine)
-            uint32_t val[R];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute
+            // The chunk's n ops over the lanes: q = ceil(n / 64) per lane for the first k lanes, q - 1 for the others (k = n - 64 (q - 1)) -- every
+            // lane decodes in slots 1 .. q - 1 and only slot 0 is a matter of the lane (the lanes below k): one masked walk iteration per
+            // chunk instead of a compare, an EXEC region and its merges in every one.
+            const uint32_t q = bcast_first((n_ops + 63u) >> 6);                       // slots in use
+            const uint32_t k = bcast_first(n_ops - 64u * (q - 1u));                   // lanes that use slot 0 (q = 0: no slot is looked at)
+            const bool first_slot = (uint32_t)lane < k;
+            // rank of the op in my slot i: lane (q - 1) + min(lane, k) + i - (slot 0 unused: 1)
+            const uint32_t r_slot0 = q ? (uint32_t)lane * (q - 1u) + ((uint32_t)lane < k ? (uint32_t)lane : k) - (first_slot ? 0u : 1u) : 0u;
+            const list_t* my_starts = list + r_slot0;   // (the start of the op in my slot i: my_starts[i])
+            uint32_t val[R];   // pixel after my i-th op, relative to the pixel entering my lane unless absolute -- and, until the op is decoded, its start
             uint32_t meta[R];  // pixels before the op inside my lane (CL_BITS) | cnt (11) << CL_BITS
             uint32_t amask[R]; // byte mask of the channels of val[] that are absolute
+            // (all eight starts fetched at once, into the registers their slots' pixels will take: one LDS round trip less in every iteration's
+            // chain of five; what lies behind the chunk's last start is never looked at)
+#pragma unroll
+            for (int i = 0; i < R; ++i) val[i] = my_starts[i];
             Xf T{0u, 0u};
             uint32_t cl = 0, longest = 0, info_or = 0;
             static_for<0, R>([&](auto i_tag) -> bool {
                 constexpr int i = decltype(i_tag)::value;
                 if ((uint32_t)i >= q) return false;
-                asm volatile("" : "=v"(val[i]), "=v"(amask[i]));   // (read later only where meta says the slot holds an op)
-                meta[i] = cl;                                      // no op in this slot of mine: zero pixels
-                if ((uint32_t)i < mine) {
-                    const uint32_t pos = my_starts[i];
+                const uint32_t pos = val[i];
+                if (i == 0) {
+                    asm volatile("" : "=v"(amask[i]));             // (read later only where meta says the slot holds an op)
+                    meta[i] = 0;                                   // no op in this slot of mine: zero pixels
+                }
+                if (i != 0 || first_slot) {
                     uint32_t lo, hi;
                     window(cb_addr + pos, lo, hi);
                     const u32x4 e = *(lcptr128)(uintptr_t)(optab_addr + (lo & 0xffu) * 16u);
@@ -466,6 +502,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         const uint32_t m = meta[i], am = amask[i];
                         const uint32_t v = add8(lane_px & ~am, val[i]);
                         const uint32_t off = lane_off + ((m & CL_MASK) << 2);
+#ifdef SQOA_DBG_BAL_NOSTORE   // timing experiments only (wrong output)
+                        asm volatile("" :: "v"(off), "v"(v), "v"(m), "s"(obase), "s"(exec_in));
+                        if (false)
+#endif
                         asm volatile(
                             "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // cnt >= 1
                             "global_store_dword %[off], %[v], %[base]\n\t"
