@@ -108,7 +108,15 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #define SQOA_BAL_LIST32 1
 #endif
     typedef std::conditional_t<SQOA_BAL_LIST32 != 0, uint32_t, uint16_t> list_t;
-    __shared__ list_t s_list[W][64 * R + 2 * R];   // (+ room for the reads of the lanes behind the last start, and one entry in front)   // per wave: byte offset in the chunk of the op start of every rank
+#ifndef SQOA_BAL_LDS_STORES
+#define SQOA_BAL_LDS_STORES 1
+#endif
+    // One region per wave, used twice in a chunk: first as the LIST of op starts (64 R entries, + room for the reads of the lanes behind the
+    // last start and one entry in front), then -- the walk has read the list -- as the chunk's PIXELS in position order (a chunk of literal
+    // ops and pixel pairs is 1.5 stream bytes a pixel or more: 683 pixels, + two dwords behind for the last op's pair write and two to dump)
+    constexpr int PIX_CAP = SQOA_BAL_LDS_STORES ? 704 : 0;
+    constexpr int SCR_DW = (64 * R + 2 * R) * (int)sizeof(list_t) / 4 > PIX_CAP + 8 ? (64 * R + 2 * R) * (int)sizeof(list_t) / 4 : PIX_CAP + 8;
+    __shared__ __attribute__((aligned(16))) uint32_t s_scr[W][SCR_DW];   // per wave: byte offset in the chunk of the op start of every rank
     __shared__ unsigned long long s_parse[2][W];
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #define BPHASE(k) do { } while (0)
 #endif
     uint32_t* lds = s_bytes[w];
-    list_t* list = s_list[w] + R;
+    list_t* list = reinterpret_cast<list_t*>(s_scr[w]) + R;
     typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
     typedef const __attribute__((address_space(1))) u32x4_a4* gcptr128u;
     u32x4 stg4 = {0u, 0u, 0u, 0u};
@@ -296,7 +304,13 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
         for (int k = 0; k < LB / 4; ++k) asm volatile("" : "+v"(qd[k]));
         uint32_t M;   // bit k: an op (a walk iteration) starts at my byte k
+#ifdef SQOA_DBG_BAL_NOSTARTS
+        M = 0x1111u; asm volatile("" : "+v"(M));
+        uint32_t trouble = 0;
+        if (false)
+#else
         uint32_t trouble = 0;   // (last chunks only: X is where their dead bytes lead anyway)
+#endif
         {
             uint32_t nxt[LB / 4];   // byte i of word w: the state BEHIND my byte 4 w + i
             uint32_t st = lst;
@@ -465,7 +479,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             // ---- wave scans: pixel positions and pixel transforms of the lanes below ------------
             const uint32_t cinc = wave_incl_scan(cl);
             const uint32_t ctot = bcast_lane(cinc, 63);
+#ifdef SQOA_DBG_BAL_NOXFSCAN
+            const Xf Ti = T;
+#else
             const Xf Ti = wave_xf_scan(T);
+#endif
             const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
             const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
             // ---- entry position / pixel from the chain, publish exits, store ------------------
@@ -490,7 +508,54 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
                 const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
                 const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
-                if (plain) {  // the common piece: literal ops only, nothing clipped, 4-byte pixels: one store per op slot
+                if (plain && SQOA_BAL_LDS_STORES && ctot <= (uint32_t)PIX_CAP) {
+                    // The common chunk: literal ops and pixel pairs only, nothing clipped, 4-byte pixels.  One store per op slot straight to
+                    // memory is 2 q instructions of 64 scattered dwords each (and half of them for the pairs' second pixels, nearly empty):
+                    // the address pipe's time, not the lanes', is what they cost (without them: -5.8 %).  The pixels go to LDS in position
+                    // order instead -- every slot writes its pixel AND the one behind it: its own again where the op is a pair, else the NEXT
+                    // op's (the next slot's; the next lane's first for the last slot), so that every writer of a position writes the same
+                    // value and no predicate is needed -- and leave as 16-byte pieces, 4 KB a store instruction.
+                    const uint32_t scr_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_scr[w];
+                    static_for<0, R>([&](auto i_tag) -> bool {
+                        constexpr int i = decltype(i_tag)::value;
+                        if ((uint32_t)i >= q) return false;
+                        val[i] = add8(lane_px & ~amask[i], val[i]);
+                        return true;
+                    });
+                    const uint32_t vfirst = first_slot ? val[0] : val[1];
+                    const uint32_t vnext_lane = shift_down1(vfirst, 0u);
+                    const uint32_t my_addr = scr_addr + ((cinc - cl) << 2);
+                    static_for<0, R>([&](auto i_tag) -> bool {
+                        constexpr int i = decltype(i_tag)::value;
+                        if ((uint32_t)i >= q) return false;
+                        const uint32_t m = meta[i];
+                        uint32_t a = my_addr + ((m & CL_MASK) << 2);
+                        if (i == 0) a = first_slot ? a : scr_addr + 4u * (uint32_t)(PIX_CAP + 4);   // (no op in my slot 0: to the dump words)
+                        const uint32_t vn = (uint32_t)i + 1u == q ? vnext_lane : val[i + 1 < R ? i + 1 : i];
+                        const uint32_t pairm = (uint32_t)((int32_t)(m << (31 - (CL_BITS + 1))) >> 31);        // ~0: cnt == 2
+                        const uint32_t sec = (val[i] & pairm) | (vn & ~pairm);
+                        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(val[i]), "v"(sec) : "memory");
+                        return true;
+                    });
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        typedef u32x4 u32x4_una __attribute__((aligned(4)));
+                        typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
+                        uint32_t lane;   // (opaque: see load_chunk)
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+                        const uint32_t* pix = s_scr[w];
+                        for (uint32_t x0 = 0; x0 < ctot; x0 += 256u) {
+                            const uint32_t x = x0 + 4u * lane;
+                            gptr32 o = (gptr32)out + pos_in + x;
+                            if (x + 4u <= ctot) *(gptr128u)o = *reinterpret_cast<const u32x4*>(pix + x);
+                            else if (x < ctot) {                                              // the chunk's last one to three pixels
+                                o[0] = pix[x];
+                                if (x + 1u < ctot) o[1] = pix[x + 1];
+                                if (x + 2u < ctot) o[2] = pix[x + 2];
+                            }
+                        }
+                    }
+                } else if (plain) {  // (the same straight to memory: one store per op slot)
                     // (hand-written as in decode_wave_kernel: the two predicates narrow EXEC directly, the stores take the image base from an
                     // SGPR pair and a 32-bit byte offset, EXEC is put back once, to what it was on entry)
                     const uint32_t lane_off = lane_p << 2;
