@@ -113,8 +113,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #endif
     // One region per wave, used twice in a chunk: first as the LIST of op starts (64 R entries, + room for the reads of the lanes behind the
     // last start and one entry in front), then -- the walk has read the list -- as the chunk's PIXELS in position order (a chunk of literal
-    // ops and pixel pairs is 1.5 stream bytes a pixel or more: 683 pixels, + two dwords behind for the last op's pair write and two to dump)
-    constexpr int PIX_CAP = SQOA_BAL_LDS_STORES ? 704 : 0;
+    // ops and pixel pairs is 1.5 stream bytes a pixel or more: 683 pixels; RUNs add theirs; + two dwords behind for the last op's pair write, two to dump)
+    constexpr int PIX_CAP = SQOA_BAL_LDS_STORES ? 768 : 0;
     constexpr int SCR_DW = (64 * R + 2 * R) * (int)sizeof(list_t) / 4 > PIX_CAP + 8 ? (64 * R + 2 * R) * (int)sizeof(list_t) / 4 : PIX_CAP + 8;
     __shared__ __attribute__((aligned(16))) uint32_t s_scr[W][SCR_DW];   // per wave: byte offset in the chunk of the op start of every rank
     __shared__ unsigned long long s_parse[2][W];
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
             if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
             else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }   // mono, QOI-compat, 1 / 2 channels out: the kernels behind
+            else if (oc != 4 || (job.dst & 3ull)) { res->status = SQOA_HIP_ST_INTERNAL; path = 2; }   // (the plan launches this kernel for four channels to dword-aligned addresses only)
         }
         s_path = path;
     }
@@ -179,12 +180,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
     const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
     const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
-    const uint32_t hc = src[12];
     const uint32_t N = bcast_first(hw * hh);
-    const int oc = (int)bcast_first(job.desc.channels ? job.desc.channels : 3u + ((hc & 1u) ? 0u : 1u));
+    constexpr int oc = 4;   // output channels (the header check above)
     // Streams packed back to back (sqoa_hip_pack) start at any byte address: all stream offsets below are relative to the
     // dword-aligned address at or in front of the stream; the `soff` bytes in front of it are loaded but never looked at.
-    const bool dw_out = (job.dst & 3ull) == 0;  // 4-channel pixels can be stored as dwords
     const uint32_t soff = (uint32_t)(job.src & 3ull);
     gcptr8 srca = src - soff;
     const uint32_t size_a = size + soff;
@@ -243,7 +242,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         constexpr bool IN = decltype(in_tag)::value;
         BPHASE(7);
         const bool more = c + W < nchunks;
+#ifndef SQOA_BAL_PREFETCH_LATE
+#define SQOA_BAL_PREFETCH_LATE 0   // (held from the top of the chunk to the end of its walk: 2.625 ms; from the end of the walk to the end of the chunk: 2.662)
+#endif
+#if !SQOA_BAL_PREFETCH_LATE
         if (more) load_chunk(c + W);
+#endif
         const uint32_t gs = p0 + c * CHUNK;               // stream offset of chunk byte 0
         const bool last_chunk = IN ? false : c == nchunks - 1;
         const uint32_t my0 = gs + LB * lane;
@@ -474,7 +478,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
                 return 0u;
             }
-            if (more) stage();   // the walk was the last reader of this chunk's bytes
+#if SQOA_BAL_PREFETCH_LATE
+            if (more) load_chunk(c + W);   // (late: the prefetched dwords are held through the scans and the stores, not through the parse and the walk)
+#else
+            if (more) stage();
+#endif
             BPHASE(3);
             // ---- wave scans: pixel positions and pixel transforms of the lanes below ------------
             const uint32_t cinc = wave_incl_scan(cl);
@@ -505,119 +513,136 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (pos_in < N) {
+                // ---- the chunk's pixels: to LDS in position order, out as 16-byte pieces --------------------------------------------------
+                // One store per op slot straight to memory -- what decode_wave_kernel does -- is 2 q instructions of 64 scattered dwords each
+                // (half of them, for the second pixel of pixel pairs, nearly empty) and one more per RUN (three chunks in four of the headline
+                // batch hold a RUN or two): the address pipe's time, not the lanes', is what they cost.  Here every slot writes its pixel into
+                // the wave's LDS region at the pixel's position in the chunk AND the pixel behind it: its own again where the op covers two
+                // pixels or more, else the NEXT op's (the next slot's; the next lane's first op's for the last slot) -- every writer of a
+                // position writes the same value, so no predicate and no order is needed; what a RUN covers behind its first two pixels is
+                // filled in by the whole wave (seqoia.h:723-725); then every lane takes four consecutive pixels back and stores them as one
+                // piece, 4 KB a store instruction.  A chunk of more than PIX_CAP pixels (long RUNs) goes through the region in windows.
                 const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
-                const uint32_t lane_p = pos_in + cinc - cl;         // pixel index of my first op
-                const bool plain = oc == 4 && dw_out && pos_in + ctot <= N && __ballot(longest > 2u) == 0ull;
-                if (plain && SQOA_BAL_LDS_STORES && ctot <= (uint32_t)PIX_CAP) {
-                    // The common chunk: literal ops and pixel pairs only, nothing clipped, 4-byte pixels.  One store per op slot straight to
-                    // memory is 2 q instructions of 64 scattered dwords each (and half of them for the pairs' second pixels, nearly empty):
-                    // the address pipe's time, not the lanes', is what they cost (without them: -5.8 %).  The pixels go to LDS in position
-                    // order instead -- every slot writes its pixel AND the one behind it: its own again where the op is a pair, else the NEXT
-                    // op's (the next slot's; the next lane's first for the last slot), so that every writer of a position writes the same
-                    // value and no predicate is needed -- and leave as 16-byte pieces, 4 KB a store instruction.
-                    const uint32_t scr_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_scr[w];
-                    static_for<0, R>([&](auto i_tag) -> bool {
-                        constexpr int i = decltype(i_tag)::value;
-                        if ((uint32_t)i >= q) return false;
-                        val[i] = add8(lane_px & ~amask[i], val[i]);
-                        return true;
-                    });
-                    const uint32_t vfirst = first_slot ? val[0] : val[1];
-                    const uint32_t vnext_lane = shift_down1(vfirst, 0u);
-                    const uint32_t my_addr = scr_addr + ((cinc - cl) << 2);
+                const uint32_t total = pos_in + ctot > N ? N - pos_in : ctot;   // (the image's last chunk: pixels behind the image's end do not exist)
+                const bool any_run = __ballot(longest > 2u) != 0ull;
+                const uint32_t scr_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_scr[w];
+                uint32_t* pix = s_scr[w];
+                static_for<0, R>([&](auto i_tag) -> bool {
+                    constexpr int i = decltype(i_tag)::value;
+                    if ((uint32_t)i >= q) return false;
+                    val[i] = add8(lane_px & ~amask[i], val[i]);     // the slot's pixel
+                    return true;
+                });
+                const uint32_t vfirst = first_slot ? val[0] : val[1];
+                const uint32_t vnext_lane = shift_down1(vfirst, 0u);
+                const uint32_t my_rel = cinc - cl;                   // the chunk's pixel my first op starts at
+                constexpr uint32_t DUMP = 4u * (uint32_t)(PIX_CAP + 4);
+                // pixels [wb, wb + n) of the chunk, which lie in the region, to memory
+                auto read_back = [&](uint32_t wb, uint32_t n) {
+                    typedef u32x4 u32x4_una __attribute__((aligned(4)));
+                    typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
+                    uint32_t lane;   // (opaque: see load_chunk)
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+                    {
+                        for (uint32_t x0 = 0; x0 < n; x0 += 256u) {
+                            const uint32_t x = x0 + 4u * lane;
+                            gptr32 o = (gptr32)out + pos_in + wb + x;
+                            if (x + 4u <= n) *(gptr128u)o = *reinterpret_cast<const u32x4*>(pix + x);
+                            else if (x < n) {                                              // the last one to three pixels
+                                o[0] = pix[x];
+                                if (x + 1u < n) o[1] = pix[x + 1];
+                                if (x + 2u < n) o[2] = pix[x + 2];
+                            }
+                        }
+                    }
+                };
+                if (ctot <= (uint32_t)PIX_CAP) {   // the common chunk: one window, every position inside it
+                    const uint32_t my_addr = scr_addr + (my_rel << 2);
                     static_for<0, R>([&](auto i_tag) -> bool {
                         constexpr int i = decltype(i_tag)::value;
                         if ((uint32_t)i >= q) return false;
                         const uint32_t m = meta[i];
                         uint32_t a = my_addr + ((m & CL_MASK) << 2);
-                        if (i == 0) a = first_slot ? a : scr_addr + 4u * (uint32_t)(PIX_CAP + 4);   // (no op in my slot 0: to the dump words)
+                        if (i == 0) a = first_slot ? a : scr_addr + DUMP;                                  // (no op in my slot 0: to the dump words)
                         const uint32_t vn = (uint32_t)i + 1u == q ? vnext_lane : val[i + 1 < R ? i + 1 : i];
-                        const uint32_t pairm = (uint32_t)((int32_t)(m << (31 - (CL_BITS + 1))) >> 31);        // ~0: cnt == 2
+                        const uint32_t pairm = sra31(0u - (m >> (CL_BITS + 1)));                              // ~0: cnt >= 2
                         const uint32_t sec = (val[i] & pairm) | (vn & ~pairm);
                         asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(val[i]), "v"(sec) : "memory");
                         return true;
                     });
-                    __builtin_amdgcn_wave_barrier();
-                    {
-                        typedef u32x4 u32x4_una __attribute__((aligned(4)));
-                        typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
-                        uint32_t lane;   // (opaque: see load_chunk)
-                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-                        const uint32_t* pix = s_scr[w];
-                        for (uint32_t x0 = 0; x0 < ctot; x0 += 256u) {
-                            const uint32_t x = x0 + 4u * lane;
-                            gptr32 o = (gptr32)out + pos_in + x;
-                            if (x + 4u <= ctot) *(gptr128u)o = *reinterpret_cast<const u32x4*>(pix + x);
-                            else if (x < ctot) {                                              // the chunk's last one to three pixels
-                                o[0] = pix[x];
-                                if (x + 1u < ctot) o[1] = pix[x + 1];
-                                if (x + 2u < ctot) o[2] = pix[x + 2];
-                            }
-                        }
-                    }
-                } else if (plain) {  // (the same straight to memory: one store per op slot)
-                    // (hand-written as in decode_wave_kernel: the two predicates narrow EXEC directly, the stores take the image base from an
-                    // SGPR pair and a 32-bit byte offset, EXEC is put back once, to what it was on entry)
-                    const uint32_t lane_off = lane_p << 2;
-                    const unsigned long long obase = job.dst;
-                    const unsigned long long exec_in = __builtin_amdgcn_read_exec();
-                    static_for<0, R>([&](auto i_tag) -> bool {
-                        constexpr int i = decltype(i_tag)::value;
-                        if ((uint32_t)i >= q) return false;
-                        const uint32_t m = meta[i], am = amask[i];
-                        const uint32_t v = add8(lane_px & ~am, val[i]);
-                        const uint32_t off = lane_off + ((m & CL_MASK) << 2);
-#ifdef SQOA_DBG_BAL_NOSTORE   // timing experiments only (wrong output)
-                        asm volatile("" :: "v"(off), "v"(v), "v"(m), "s"(obase), "s"(exec_in));
-                        if (false)
-#endif
-                        asm volatile(
-                            "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // cnt >= 1
-                            "global_store_dword %[off], %[v], %[base]\n\t"
-                            "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // cnt == 2: a literal op and the one-pixel run behind it
-                            "global_store_dword %[off], %[v], %[base] offset:4\n\t"
-                            "s_mov_b64 exec, %[ex]"
-                            :: [m] "v"(m), [off] "v"(off), [v] "v"(v), [base] "s"(obase), [ex] "s"(exec_in), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
-                        return true;
-                    });
-                    asm volatile("s_nop 4");   // (a VALU write of EXEC, v_cmpx, wants 5 wait states in front of a DPP instruction)
-                } else {
-                    auto store_ops = [&](auto oc_tag) {
-                        constexpr int OC = decltype(oc_tag)::value;
+                    if (any_run) {
                         static_for<0, R>([&](auto i_tag) -> bool {
                             constexpr int i = decltype(i_tag)::value;
                             if ((uint32_t)i >= q) return false;
-                            const uint32_t m = meta[i];
-                            const uint32_t cnt = m >> CL_BITS;
-                            const uint32_t P = lane_p + (m & CL_MASK);
-                            const uint32_t am = amask[i];
-                            const uint32_t v = add8(lane_px & ~am, val[i]);
-                            if (cnt >= 1u && cnt <= 2u && P < N) put_pixel<OC>(out, P, v);
-                            if (cnt == 2u && P + 1u < N) put_pixel<OC>(out, P + 1u, v);
-                            unsigned long long runs = __ballot(cnt > 2u && P < N);
-                            while (runs) {  // expand runs with the whole wave (seqoia.h:723-725)
+                            const uint32_t m = meta[i], cnt = m >> CL_BITS;
+                            unsigned long long runs = __ballot(cnt > 2u);
+                            while (runs) {
                                 const int l = __builtin_ctzll(runs);
                                 runs &= runs - 1ull;
-                                const uint32_t rp = bcast_lane(P, l), rv = bcast_lane(v, l);
-                                uint32_t rc = bcast_lane(cnt, l);
-                                if (rp + rc > N) rc = N - rp;
-                                fill_pixels<OC>(out, rp, rc, rv, lane);
+                                const uint32_t rp = bcast_lane(my_rel + (m & CL_MASK), l) + 2u, rc = bcast_lane(cnt, l) - 2u, rv = bcast_lane(val[i], l);
+                                for (uint32_t t = (uint32_t)lane; t < rc; t += 64u) pix[rp + t] = rv;
                             }
                             return true;
                         });
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    read_back(0u, total);
+                } else {
+                    // A chunk of more pixels than the region holds (long RUNs: a flat stretch).  The pixels of its literal ops go straight to
+                    // memory, one store per slot and pixel; its RUNs are listed in the region, four slots at a time -- (position, count), pixel
+                    // -- and one loop expands them, 64 pixels a store.  (Not a path to be fast on: the plan sends RUN-heavy batches to
+                    // decode_wave_kernel's position-major variant; but compact -- as eight unrolled slots with a fill loop each it cost the
+                    // walk its registers.)
+                    const unsigned long long obase = job.dst;
+                    const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+                    const uint32_t lane_off = (pos_in + my_rel) << 2;
+                    auto half = [&](auto h_tag) {
+                        constexpr int H = decltype(h_tag)::value;
+                        uint32_t nruns = 0;
+                        static_for<4 * H, 4 * H + 4>([&](auto i_tag) -> bool {
+                            constexpr int i = decltype(i_tag)::value;
+                            if ((uint32_t)i >= q) return false;
+                            uint32_t m = meta[i];
+                            const uint32_t P = pos_in + my_rel + (m & CL_MASK), cnt = m >> CL_BITS;
+                            // (behind the image's end nothing exists: the slot's count as far as the image reaches)
+                            const uint32_t room = P < N ? N - P : 0u;
+                            const uint32_t c1 = cnt < room ? cnt : room;
+                            const uint32_t mm = (m & CL_MASK) | ((c1 < 2u ? c1 : 2u) << CL_BITS);
+                            const uint32_t off = lane_off + ((m & CL_MASK) << 2);
+                            asm volatile(
+                                "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // a pixel
+                                "global_store_dword %[off], %[v], %[base]\n\t"
+                                "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // a second one
+                                "global_store_dword %[off], %[v], %[base] offset:4\n\t"
+                                "s_mov_b64 exec, %[ex]\n\t"
+                                "s_nop 4"
+                                :: [m] "v"(mm), [off] "v"(off), [v] "v"(val[i]), [base] "s"(obase), [ex] "s"(exec_in), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+                            const bool isrun = c1 > 2u;
+                            const unsigned long long rm = __ballot(isrun);
+                            const uint32_t rk = nruns + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                            if (isrun) { pix[rk] = P + 2u; pix[256 + rk] = c1 - 2u; pix[512 + rk] = val[i]; }
+                            nruns += (uint32_t)__builtin_popcountll(rm);
+                            return true;
+                        });
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t r = 0; r < nruns; ++r) {
+                            const uint32_t rp = bcast_first(pix[r]), rc = bcast_first(pix[256 + r]), rv = bcast_first(pix[512 + r]);
+                            for (uint32_t t = (uint32_t)lane; t < rc; t += 64u) ((gptr32)out)[rp + t] = rv;
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     };
-                    if (oc == 4 && dw_out) store_ops(std::integral_constant<int, 4>{});
-                    else if (oc == 4) store_ops(std::integral_constant<int, 40>{});
-                    else store_ops(std::integral_constant<int, 3>{});
+                    half(std::integral_constant<int, 0>{});
+                    if (q > 4u) half(std::integral_constant<int, 1>{});
                 }
             }
             BPHASE(5);
         }
+#if SQOA_BAL_PREFETCH_LATE
+        if (more) stage();
+#endif
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
-                if (oc == 4 && dw_out) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
-                else if (oc == 4) fill_pixels<40>(out, pos_out, N - pos_out, exit_v, lane);
-                else fill_pixels<3>(out, pos_out, N - pos_out, exit_v, lane);
+                fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
             }
             if (lane == 0) res->len = (int)(N * (uint32_t)oc);
         }

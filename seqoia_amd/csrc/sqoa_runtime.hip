@@ -450,12 +450,13 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             auto shape_of = [&](size_t a, size_t b) -> int {
                 if (a >= b) return 0;
                 unsigned long long by = 0, by4 = 0, px = 0;
-                bool shaped = true;
+                bool shaped = true, all4 = true;
                 for (size_t k = a; k < b; ++k) {
                     const sqoa_hip_job& j = jobs[ids_a[k]];
                     by += j.src_size;
                     px += (unsigned long long)j.desc.width * j.desc.height;
                     if (j.desc.channels == 4) by4 += j.src_size;
+                    if (j.desc.channels != 4 || (j.dst & 3ull)) all4 = false;
                     if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
                 }
                 const bool roomy = by / (b - a) >= (12u << 10);
@@ -464,8 +465,10 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
                 //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
                 //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
+                //    -- a kernel for four channels to dword-aligned addresses only, so only for plans whose every job is that
                 int bal = wide && !sweep && !p->small;
                 if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
+                bal = bal && all4;
                 return p->small | wide << 1 | sweep << 2 | bal << 3;
             };
             p->shape = shape_of(c0, ids_a.size());
