@@ -69,21 +69,31 @@ SQOA_DEV void static_for(F&& f) {
         if (f(std::integral_constant<int, I>{})) static_for<I + 1, N>(f);
     }
 }
+#ifndef SQOA_BAL_HL_VGPR   // the SWAR constants of the packed-byte adds in two VGPRs: as literals the compiler parks them in SGPRs, and an SGPR operand makes a fast-class instruction a slow one
+#define SQOA_BAL_HL_VGPR 0
+#endif
+#if SQOA_BAL_HL_VGPR
+#define BHL , hl
+#define BHLP , HL hl
+#else
+#define BHL
+#define BHLP
+#endif
 template <int CTRL, int ROWMASK>
-SQOA_DEV Xf xf_scan_step(Xf T) {
+SQOA_DEV Xf xf_scan_step(Xf T BHLP) {
     Xf P;  // the transform of the lanes below, identity (all zero) where there is none
     constexpr bool BC = ROWMASK == 0xf;
     P.v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v, CTRL, ROWMASK, 0xf, BC);
     P.abs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.abs, CTRL, ROWMASK, 0xf, BC);
-    return xf_then(P, T);
+    return xf_then(P, T BHL);
 }
-SQOA_DEV Xf wave_xf_scan(Xf T) {
-    T = xf_scan_step<DPP_ROW_SHR + 1, 0xf>(T);
-    T = xf_scan_step<DPP_ROW_SHR + 2, 0xf>(T);
-    T = xf_scan_step<DPP_ROW_SHR + 4, 0xf>(T);
-    T = xf_scan_step<DPP_ROW_SHR + 8, 0xf>(T);
-    T = xf_scan_step<DPP_ROW_BCAST15, 0xa>(T);
-    T = xf_scan_step<DPP_ROW_BCAST31, 0xc>(T);
+SQOA_DEV Xf wave_xf_scan(Xf T BHLP) {
+    T = xf_scan_step<DPP_ROW_SHR + 1, 0xf>(T BHL);
+    T = xf_scan_step<DPP_ROW_SHR + 2, 0xf>(T BHL);
+    T = xf_scan_step<DPP_ROW_SHR + 4, 0xf>(T BHL);
+    T = xf_scan_step<DPP_ROW_SHR + 8, 0xf>(T BHL);
+    T = xf_scan_step<DPP_ROW_BCAST15, 0xa>(T BHL);
+    T = xf_scan_step<DPP_ROW_BCAST31, 0xc>(T BHL);
     return T;
 }
 
@@ -417,6 +427,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
         };
         uint32_t pos_in = 0, px_in = kPxInit, pos_out, exit_v;
+#if SQOA_BAL_HL_VGPR
+        HL hl;
+        asm volatile("v_mov_b32 %0, 0x80808080" : "=v"(hl.H));
+        asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(hl.L));
+#endif
         {
             // The chunk's n ops over the lanes: q = ceil(n / 64) per lane for the first k lanes, q - 1 for the others (k = n - 64 (q - 1)) -- every
             // lane decodes in slots 1 .. q - 1 and only slot 0 is a matter of the lane (the lanes below k): one masked walk iteration per
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     const uint32_t bse = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
                     const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;                         // LUMA, seqoia.h:761-769
                     const uint32_t d8 = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u) | da24;
-                    T = xf_then(T, Xf{(d8 & ~setm) | (bse & setm), setm});
+                    T = xf_then(T, Xf{(d8 & ~setm) | (bse & setm), setm} BHL);
                     val[i] = T.v;
                     meta[i] = cl | cnt << CL_BITS;
                     amask[i] = T.abs;
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #ifdef SQOA_DBG_BAL_NOXFSCAN
             const Xf Ti = T;
 #else
-            const Xf Ti = wave_xf_scan(T);
+            const Xf Ti = wave_xf_scan(T BHL);
 #endif
             const Xf Tg{bcast_lane(Ti.v, 63), bcast_lane(Ti.abs, 63)};
             const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
@@ -506,7 +521,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 }
             }
             BPHASE(4);
-            exit_v = xf_apply(Tg, px_in);
+            exit_v = xf_apply(Tg, px_in);   // (wave-uniform: scalar arithmetic)
             pos_out = pos_in + ctot > N ? N : pos_in + ctot;
             if (!last_chunk && lane == 0) {
                 __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 // position writes the same value, so no predicate and no order is needed; what a RUN covers behind its first two pixels is
                 // filled in by the whole wave (seqoia.h:723-725); then every lane takes four consecutive pixels back and stores them as one
                 // piece, 4 KB a store instruction.  A chunk of more than PIX_CAP pixels (long RUNs) goes through the region in windows.
-                const uint32_t lane_px = xf_apply(Tx, px_in);       // pixel entering my lane
+                const uint32_t lane_px = xf_apply(Tx, px_in BHL);       // pixel entering my lane
                 const uint32_t total = pos_in + ctot > N ? N - pos_in : ctot;   // (the image's last chunk: pixels behind the image's end do not exist)
                 const bool any_run = __ballot(longest > 2u) != 0ull;
                 const uint32_t scr_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_scr[w];
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 static_for<0, R>([&](auto i_tag) -> bool {
                     constexpr int i = decltype(i_tag)::value;
                     if ((uint32_t)i >= q) return false;
-                    val[i] = add8(lane_px & ~amask[i], val[i]);     // the slot's pixel
+                    val[i] = add8(lane_px & ~amask[i], val[i] BHL);     // the slot's pixel
                     return true;
                 });
                 const uint32_t vfirst = first_slot ? val[0] : val[1];
@@ -556,6 +571,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         }
                     }
                 };
+                const unsigned long long exec_in = __builtin_amdgcn_read_exec();
                 if (ctot <= (uint32_t)PIX_CAP) {   // the common chunk: one window, every position inside it
                     const uint32_t my_addr = scr_addr + (my_rel << 2);
                     static_for<0, R>([&](auto i_tag) -> bool {
@@ -564,10 +580,24 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         const uint32_t m = meta[i];
                         uint32_t a = my_addr + ((m & CL_MASK) << 2);
                         if (i == 0) a = first_slot ? a : scr_addr + DUMP;                                  // (no op in my slot 0: to the dump words)
+#ifndef SQOA_BAL_PIX_WRITE2
+#define SQOA_BAL_PIX_WRITE2 0
+#endif
+#if SQOA_BAL_PIX_WRITE2
                         const uint32_t vn = (uint32_t)i + 1u == q ? vnext_lane : val[i + 1 < R ? i + 1 : i];
                         const uint32_t pairm = sra31(0u - (m >> (CL_BITS + 1)));                              // ~0: cnt >= 2
                         const uint32_t sec = (val[i] & pairm) | (vn & ~pairm);
                         asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(val[i]), "v"(sec) : "memory");
+#else
+                        // (the second dword only where the op covers it: half the bytes into the LDS pipe, which this kernel keeps 70 % busy)
+                        asm volatile(
+                            "ds_write_b32 %[a], %[v]\n\t"
+                            "v_cmpx_lt_u32_e32 vcc, %[c2], %[m]\n\t"           // cnt >= 2
+                            "ds_write_b32 %[a], %[v] offset:4\n\t"
+                            "s_mov_b64 exec, %[ex]\n\t"
+                            "s_nop 4"
+                            :: [m] "v"(m), [a] "v"(a), [v] "v"(val[i]), [ex] "s"(exec_in), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+#endif
                         return true;
                     });
                     if (any_run) {
@@ -594,7 +624,6 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // decode_wave_kernel's position-major variant; but compact -- as eight unrolled slots with a fill loop each it cost the
                     // walk its registers.)
                     const unsigned long long obase = job.dst;
-                    const unsigned long long exec_in = __builtin_amdgcn_read_exec();
                     const uint32_t lane_off = (pos_in + my_rel) << 2;
                     auto half = [&](auto h_tag) {
                         constexpr int H = decltype(h_tag)::value;
