@@ -218,11 +218,12 @@ SQOA_DEV void lds_dma(unsigned long long gaddr, uint8_t* lds_dst, bool half_seco
             "s_mov_b32 m0, %[lds]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "global_load_lds_dwordx4 %[off], %[base]\n\t"
+            "s_mov_b32 vcc_hi, exec_hi\n\t"                   // (EXEC goes back to what it was, whatever that is: kept in VCC, which the block clobbers)
             "s_mov_b32 exec_hi, 0\n\t"                        // lanes 0..31: bytes [1024, 1536)
             "global_load_lds_dwordx4 %[off], %[base] offset:1024\n\t"
-            "s_mov_b32 exec_hi, -1\n\t"
+            "s_mov_b32 exec_hi, vcc_hi\n\t"
             "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep), [off] "=&v"(off) : [base] "s"(gaddr), [lds] "s"(lds_addr) : "memory");
+            : [keep] "=&s"(keep), [off] "=&v"(off) : [base] "s"(gaddr), [lds] "s"(lds_addr) : "memory", "vcc");
     }
 }
 

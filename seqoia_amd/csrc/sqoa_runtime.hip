@@ -107,8 +107,6 @@ struct sqoa_hip_plan {
     int n = 0, cap = 0;
     sqoa_hip_job* d_jobs = nullptr;
     sqoa_hip_result* d_results = nullptr;
-    sqoa_hip_result* d_init = nullptr;  // staging of the result rows as a fill leaves them (BADARG / OVERFLOW rows pre-filled): copied to d_results ONCE per fill --
-                                        // a launch touches only the rows of valid jobs, and the first kernel that takes a job resets its row itself
     uint32_t* d_word = nullptr;         // one scratch word (the framing hint of the multi-pass streams, plan_fill)
     int* d_ids = nullptr;               // job indices grouped by kernel variant
     int n_sqoa = 0, n_qoi = 0;          // encode: counts per variant; decode: n_sqoa = all valid jobs
@@ -481,8 +479,9 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     if (n == 0) return 0;
     hipError_t e;
     if ((e = hipMemcpy(p->d_jobs, jobs, sizeof(sqoa_hip_job) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->d_init, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->d_results, p->d_init, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToDevice)) != hipSuccess ||
+        // (the result rows as this fill leaves them -- BADARG / OVERFLOW rows of refused jobs, zeros elsewhere --, ONCE per fill and straight from
+        // the host: a pageable-host-to-device hipMemcpy has returned only when the copy is done, which a device-to-device one need not)
+        (e = hipMemcpy(p->d_results, init.data(), sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
         (!ids_a.empty() && (e = hipMemcpy(p->d_ids, ids_a.data(), sizeof(int) * ids_a.size(), hipMemcpyHostToDevice)) != hipSuccess))
         return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan: job table upload", e);
     p->dp.any_qoi = 0;
@@ -612,7 +611,7 @@ int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, 
     const size_t jb = sizeof(sqoa_hip_job) * (size_t)(n ? n : 1), rb = sizeof(sqoa_hip_result) * (size_t)(n ? n : 1);
     hipError_t e;
     if ((e = hipMalloc((void**)&p->d_jobs, jb)) != hipSuccess || (e = hipMalloc((void**)&p->d_results, rb)) != hipSuccess ||
-        (e = hipMalloc((void**)&p->d_init, rb)) != hipSuccess || (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
         (e = hipMalloc((void**)&p->d_word, 256)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&p->ev0)) != hipSuccess ||
         (e = hipEventCreate(&p->ev1)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming)) != hipSuccess) {
@@ -639,7 +638,6 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     if (p->ev_done) hipEventDestroy(p->ev_done);
     if (p->d_jobs) hipFree(p->d_jobs);
     if (p->d_results) hipFree(p->d_results);
-    if (p->d_init) hipFree(p->d_init);
     if (p->d_word) hipFree(p->d_word);
     if (p->d_ids) hipFree(p->d_ids);
     for (void* d : {p->st.d_images, p->st.d_strips, p->st.d_cuts, p->st.d_jobs, p->st.d_ids, p->st.d_results, p->st.d_offsets, p->st.d_ws, p->st.d_qtab, p->st.d_qtin})

@@ -281,9 +281,9 @@ def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
         del dec, enc
 
 
-@pytest.mark.parametrize("rank", [0, 7])
+@pytest.mark.parametrize("rank", [0, 3, 7])
 def test_c5_rank_of_8_shard(sq, orc, rank):
-    """BASELINE configs[4] as the first and the last of its 8 ranks see it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
+    """BASELINE configs[4] as the first, a middle and the last of its 8 ranks see it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
     LPT-sharded on w*h, the rank's 8 192 images in ONE encode plan and ONE decode plan (the workload class of
     `bench.py --config c5 --gpus 8`): every status OK, every image round-trips exactly (sqoabench.c:448-455, one result per
     image as in sqoabench.c:575-628), and a sample of streams from every directory is byte-equal to the oracle's."""
@@ -310,6 +310,39 @@ def test_c5_rank_of_8_shard(sq, orc, rank):
     torch.cuda.synchronize()
     assert (wl.enc.results()["len"].astype("int64") == wl.lens).all()
     wl.close()
+
+
+def test_c4_icon_set_at_full_size(sq, orc):
+    """BASELINE configs[3] at its full size: 4 096 icon-style RGB images of 512 x 512 (RUN / BIGRUN dominated; the plan takes the wave
+    decoder's position-major store shape for them) in one encode plan and one decode plan per output channel count: every status OK,
+    every image round-trips exactly to three channels and to four (sqoabench's timed decode, sqoabench.c:490-494), every stream's length
+    and a sample of 32 streams spread over the set byte-equal to the compiled reference's, in both wire formats."""
+    import torch
+
+    n, w, h, ch = 4096, 512, 512, 3
+    px = torch.empty((n, h, w, ch), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "icon", seed=1, img0=0)
+    o = orc.best()
+    sample = list(range(0, n, n // 32))
+    for mode in (0, 1):
+        enc = sq.EncodePlan(px, qoi_compat=mode)
+        enc.launch()
+        res = enc.results()
+        assert (res["status"] == 0).all()
+        got = enc.streams(sample)
+        for k, g in zip(sample, got):
+            assert g == o.encode(orc.synth(w, h, ch, "icon", 1, k), w, h, ch, mode), (mode, k)
+        for oc in (3, 4):
+            dec = sq.DecodePlan(enc.out, res["len"], w, h, oc)
+            dec.launch()
+            dres = dec.results()
+            assert (dres["status"] == 0).all() and (dres["len"] == w * h * oc).all()
+            if oc == 3:
+                assert torch.equal(dec.out, px)
+            else:
+                assert torch.equal(dec.out[..., :3], px) and bool((dec.out[..., 3] == 255).all())
+            dec.close()
+        enc.close()
 
 
 def test_results_wait_for_a_launch_on_the_callers_stream(sq, orc):

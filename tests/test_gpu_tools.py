@@ -3,6 +3,7 @@
 benchmark with its round-trip verify (sqoabench.c:448-455)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -90,3 +91,20 @@ def test_sqoabatch_directory_roundtrip(tmp_path):
             assert (qoi / f"{name}.qoi").read_bytes() == po.best().encode(px.reshape(-1), w, h, ch, 1), name
         else:
             assert not (qoi / f"{name}.qoi").exists()
+
+
+def test_bench_rank_path_with_two_ranks_on_the_card():
+    """The real rank path of bench.py with WORLD_SIZE 2 on this box's one card (`--rehearsal`: the line says so; gloo for the timing
+    barrier / MAX and the gather of the per-image lengths): two rank processes, each with its own plans on the device, the barrier,
+    the all-reduce of the step time, the gathered lengths adding up to the bytes the ranks wrote.  (The CPU tests of tests/test_shard.py
+    run the launcher with --dry-run: no GPU work under WORLD_SIZE > 1 anywhere else.)"""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--backend", "gloo", "--images", "8", "--steps", "2",
+                        "--warmup", "1", "--no-secondary", "--no-cpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and "rehearsal" in out and out["scaling"] == "weak"
+    assert out["config"]["encoded_bytes_check"] == out["config"]["encoded_bytes_total"] > 0
+    assert out["value"] > 0 and out["steps"] == 2

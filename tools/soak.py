@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Differential soak on the GPU box: plans of random image lists (sizes 1x1 .. 900x700, 3 / 4 channels, the three synthetic
 classes plus low-entropy noise with long runs, both wire formats) through EncodeList / DecodeList under every forcing of the
-routes (SQOA_HIP_STRIPS, SQOA_HIP_MULTIPASS, and the wave decoder's shapes: SQOA_HIP_DEC_WIDE, SQOA_HIP_DEC_SWEEP), every stream and
-every decoded image against the reference (oracle/_ref).
-usage: soak.py [rounds] [seed] [seconds]      (tests/test_gpu_soak.py runs a 30-second cut of it in the -m gpu suite)"""
+routes (SQOA_HIP_STRIPS, SQOA_HIP_MULTIPASS, and the wave decoder's shapes: SQOA_HIP_DEC_WIDE, SQOA_HIP_DEC_SWEEP, SQOA_HIP_DEC_BAL), every
+stream and every decoded image against the reference (oracle/_ref).
+usage: soak.py [rounds] [seed] [seconds]      (rounds or seconds, whichever ends first; tests/test_gpu_soak.py runs 40 rounds of it in the -m gpu suite)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, seqoia_amd as sq
@@ -15,7 +15,7 @@ budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 t_start = time.time()
 o = po.best()
 assert o.kind == "reference", "the soak compares with the compiled reference (oracle/_ref)"
-checked = 0
+checked = rounds_done = 0
 for r in range(rounds):
     if time.time() - t_start > budget:
         break
@@ -42,10 +42,11 @@ for r in range(rounds):
     for mode in (0, 1):
         wants = [o.encode(raw, w, h, ch, mode) for (w, h, ch, raw) in imgs]
         # (the plan's own choices; the chip-wide routes for everything; one workgroup per image with the wave decoder at 8 bytes per
-        # lane, at 12, at 12 with the position-major store path)
-        for strips, passes, wide, sweep in (("", "", "", ""), ("1", "1", "", ""), ("0", "0", "0", "0"), ("0", "0", "1", "0"), ("0", "0", "1", "1")):
+        # lane, at 12, at 12 with the position-major store path, and the balanced kernel wherever a plan's jobs all go to four channels)
+        for strips, passes, wide, sweep, bal in (("", "", "", "", ""), ("1", "1", "", "", ""), ("0", "0", "0", "0", "0"), ("0", "0", "1", "0", "0"), ("0", "0", "1", "1", "0"),
+                                                 ("0", "0", "1", "0", "1")):
             os.environ["SQOA_HIP_STRIPS"], os.environ["SQOA_HIP_MULTIPASS"] = strips, passes
-            os.environ["SQOA_HIP_DEC_WIDE"], os.environ["SQOA_HIP_DEC_SWEEP"] = wide, sweep
+            os.environ["SQOA_HIP_DEC_WIDE"], os.environ["SQOA_HIP_DEC_SWEEP"], os.environ["SQOA_HIP_DEC_BAL"] = wide, sweep, bal
             images = [(torch.from_numpy(raw).cuda(), sq.Desc(w, h, ch, 0, mode)) for (w, h, ch, raw) in imgs]
             enc = sq.EncodeList(images)
             enc.launch()
@@ -63,9 +64,10 @@ for r in range(rounds):
                     occ = oc if oc else ch
                     want = o.decode(wants[k], occ)[0]
                     have = dec.out[dec.offsets[k] : dec.offsets[k] + w * h * occ].cpu().numpy()
-                    assert dres["status"][k] == 0 and have.tobytes() == want.tobytes(), ("decode", r, mode, passes, wide, sweep, oc, k, imgs[k][:3])
+                    assert dres["status"][k] == 0 and have.tobytes() == want.tobytes(), ("decode", r, mode, passes, wide, sweep, bal, oc, k, imgs[k][:3])
                     checked += 1
                 dec.close()
             enc.close()
     print(f"round {r}: {n} images ok", flush=True)
-print(f"soak ok: {checked} decoded images and their streams identical to the reference")
+    rounds_done = r + 1
+print(f"soak ok: {checked} decoded images and their streams identical to the reference ({rounds_done} rounds, {time.time() - t_start:.0f} s)")
