@@ -334,10 +334,10 @@ class Suite:
         self.enc.close()
 
 
-def board_power():
-    """(watts drawn, the cap, shader clock in MHz) of the busiest card the host shows in sysfs hwmon -- the one this process loads, unless a
-    neighbour on the same host is busier -- or None.  Both kernels run AT the board's power cap on MI355X (1400 W: profiles/r04_power.txt;
-    the clock the chip then holds is what `roofline.*.clock_ghz` reports from the SQ counters): one read, a few microseconds."""
+def board_power(pci=None):
+    """(watts drawn, the cap, shader clock in MHz) from sysfs hwmon of the card at PCI address `pci` ("0000:c5:00.0": this rank's own device) --
+    or, where that cannot be told, of the busiest card the host shows -- or None.  Both kernels run AT the board's power cap on MI355X
+    (1400 W: profiles/r04_power.txt).  One read, a few microseconds; called while untimed steps run on the device."""
     import glob
 
     best = None
@@ -348,9 +348,29 @@ def board_power():
             mhz = int(open(os.path.join(h, "freq1_input")).read()) / 1e6
         except (OSError, ValueError):
             continue
+        row = (round(w, 1), round(cap, 1), round(mhz))
+        if pci and os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).lower() == pci.lower():
+            return row + ("own",)
         if best is None or w > best[0]:
-            best = (round(w, 1), round(cap, 1), round(mhz))
-    return best
+            best = row
+    return best + ("busiest",) if best else None
+
+
+def in_step_times(torch, wl, work_stream, k):
+    """(encode ms, decode ms): each plan's launch INSIDE the encode -> decode step, medians over k steps, events on the stream the step runs on.
+    (A kernel behind the other one is not the kernel in a loop of its own: the board's power budget is shared -- profiles/r04_a_step_parts.txt.)"""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * k + 1)]
+    stream = work_stream.cuda_stream
+    ev[0].record(work_stream)
+    for i in range(k):
+        wl.enc.launch(stream)
+        ev[2 * i + 1].record(work_stream)
+        wl.dec.launch(stream)
+        ev[2 * i + 2].record(work_stream)
+    torch.cuda.synchronize()
+    e = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(k))
+    d = sorted(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(k))
+    return e[k // 2], d[k // 2]
 
 
 def kernel_times(wl, k):
@@ -456,8 +476,8 @@ def legacy_calls(sq, headline, runs=10):
 
 def counters_from_profile(kernel, images, size):
     """What the committed rocprofv3 PMC summary says about a headline kernel -- HBM bytes per launch, instructions retired per 64
-    pixels by kind, LDS bank-conflict cycles per active LDS cycle, the clock the chip held (SQ_BUSY_CYCLES / 32 shader engines /
-    the kernel's average duration in the same round's kernel stats) -- only when it was taken from THIS kernel source (the summary
+    pixels by kind, LDS bank-conflict cycles per active LDS cycle, the clock of the counter pass (SQ_BUSY_CYCLES / shader engines /
+    the kernel's duration in that same pass: an estimate of the timed run's), the kernel's durations by phase of the kernel-trace pass -- only when it was taken from THIS kernel source (the summary
     records the hash of seqoia_amd/csrc) on the same image shape; the bytes are scaled to this rank's number of images (the
     images are independent and equal in size: traffic is per image).  {} otherwise."""
     import hashlib
@@ -478,7 +498,7 @@ def counters_from_profile(kernel, images, size):
     # gfx950: FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md, HBM); KB
     per_launch = (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024
     out = {"traffic": int(per_launch * images / d.get("images", 1024)), "source": "profiles/pmc_hbm_latest.json"}
-    for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz", "rocprof_avg_ms", "rocprof_min_ms", "kernel"):
+    for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz_pmc_pass", "rocprof_avg_ms", "rocprof_min_ms", "rocprof_in_step_ms", "rocprof_alone_ms", "kernel"):
         if f in k:
             out[f] = k[f]
     return out
@@ -613,12 +633,21 @@ def run_rank(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    power = board_power()   # (read while the last steps are still running on the device: the launches above are asynchronous)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # board power / shader clock of this rank's card, read while a few more (untimed) steps run: outside the timed region
+    for _ in range(max(4, min(args.steps, 16))):
+        run()
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001 -- the property names vary with the torch build
+        pci = None
+    power = board_power(pci)
+    torch.cuda.synchronize()
     totals = [float(wl.pixels), float(wl.enc_bytes), float(wl.read_bytes)]
     if dist is not None:
         on = dev if args.backend == "nccl" else "cpu"
@@ -636,6 +665,7 @@ def run_rank(args):
 
     # per-kernel durations with HIP events on the stream the kernels run on (the plan's own)
     k = max(args.steps, 5)
+    enc_step_ms, dec_step_ms = in_step_times(torch, wl, work_stream, k)
     enc_ms, dec_ms = kernel_times(wl, k)
 
     if c5:
@@ -669,8 +699,10 @@ def run_rank(args):
             "launch": "hip graph replay" if graph is not None else "direct",
             "spin_up_ms_per_step": [spin_ms[0], min(spin_ms), spin_ms[-1]],  # first group of 8, fastest, last
             "spin_up_steps": spin_up,  # untimed, in front of the W warm-up steps: the clocks ramp up after the idle setup phase
-            # board power / its cap / shader clock read from sysfs while the last timed steps ran (rank 0's host view; None where hwmon is not readable)
+            # board power / its cap / shader clock from sysfs hwmon, read while untimed steps ran behind the timed region: of this rank's own card
+            # ("own": matched by PCI address) or of the busiest card the host shows; None where hwmon is not readable
             "board_power_w": power[0] if power else None, "board_power_cap_w": power[1] if power else None, "sclk_mhz_hwmon": power[2] if power else None,
+            "board_power_card": power[3] if power else None,
             "encode_mpps_rank0": round(wl.pixels / enc_ms / 1e3, 1),
             "decode_mpps_rank0": round(wl.pixels / dec_ms / 1e3, 1),
             "roofline_frac_of_n_gpus": round(total_px * args.steps / dt / (world * HBM_PEAK_GBS * 1e9 / 4), 4),
@@ -687,10 +719,14 @@ def run_rank(args):
         # from the committed PMC summary of this very source (None / absent otherwise): HBM bytes per launch, instructions retired
         # per 64 pixels by kind, LDS conflict ratio, the clock the chip held under this kernel, the kernel ALONE as rocprofv3 timed it
         row["traffic"] = pmc.get("traffic")
-        for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz"):
+        for f in ("insts_per_64px", "lds_conflict_cycles_per_active_cycle", "clock_ghz_pmc_pass"):
             if f in pmc:
                 row[f] = pmc[f]
-        if "rocprof_avg_ms" in pmc:
+        # the kernel as rocprofv3 timed it in the committed profile round, by phase: inside the timed steps / in a loop of its own (median, p10:
+        # steady state, the spin-up left out) -- `frac` recomputed from `alone.median` must reproduce the line's within the box-to-box spread
+        if "rocprof_in_step_ms" in pmc:
+            row["kernel_ms_rocprof"] = {"in_step": pmc["rocprof_in_step_ms"], "alone": pmc["rocprof_alone_ms"]}
+        elif "rocprof_avg_ms" in pmc:
             row["kernel_ms_rocprof"] = {"avg": pmc["rocprof_avg_ms"], "min": pmc["rocprof_min_ms"]}
         return row
 
@@ -705,13 +741,15 @@ def run_rank(args):
         # write traffic) the READ rate cannot exceed this fraction of the 8 TB/s peak on this content
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS / (1.0 + wl.enc_bytes / wl.read_bytes), 4),
         "plan_launch_ms": round(enc_ms, 4),
+        "in_step_ms": round(enc_step_ms, 4),   # the same launch inside the encode -> decode step (median): what `value` is made of
     }, enc_pmc)
     roof_dec = pmc_fields({
-        "kernel": dec_pmc.get("kernel", "sqoa::decode_wave_kernel<8, 0, 12>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "kernel": dec_pmc.get("kernel", "sqoa::bal::decode_bal_kernel<8, 16>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
         "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
         "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS, 4),   # all of its bytes are streaming traffic
         "plan_launch_ms": round(dec_ms, 4),
+        "in_step_ms": round(dec_step_ms, 4),
     }, dec_pmc)
     out["roofline"] = dict(roof_dec if dominant == "decode" else roof_enc)
     out["roofline"]["dominant_by_time"] = dominant

@@ -9,6 +9,17 @@
 
 #define SQOA_DEV __device__ __forceinline__
 
+// A/B builds at different code placements (tools/mkplaced.sh: -DSQOA_PAD=0 / 2 / 4 -> the kernel's body starts 0 / 8 / 16 bytes later): the
+// same source timed at three placements says how much of a difference between two variants is where their loops happen to lie against the
+// instruction fetch granularity (cdna_hip_programming.md, rule 27) -- a keep / drop decision below that band is not one.
+#define SQOA_STR2(x) #x
+#define SQOA_STR(x) SQOA_STR2(x)
+#if defined(SQOA_PAD) && SQOA_PAD > 0
+#define SQOA_PLACEMENT_PAD() asm volatile(".rept " SQOA_STR(SQOA_PAD) "\n\ts_nop 0\n\t.endr")
+#else
+#define SQOA_PLACEMENT_PAD() do { } while (0)
+#endif
+
 // s_sleep argument (x 64 cycles) between two polls of a chain word: a polling wave spends scalar-pipe slots, which the
 // kernels are short of (tools/ubench/salu_mix.hip)
 #ifndef SQOA_ENC_SPIN_SLEEP

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ unsigned long long s_px[W];
     __shared__ uint32_t s_path;  // 1 = decoded here, 2 = refused / left to the other kernels
 
+    SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ unsigned long long s_smask[64];     // resolver scratch: per index slot, the lanes of the group whose pixel hashes to it
     __shared__ uint32_t s_go;
 
+    SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     uint32_t chunk_first = 0, wg_first = 0;   // SPEC: this workgroup's first chunk, and the image's first row of the tables

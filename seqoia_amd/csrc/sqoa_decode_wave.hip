@@ -299,6 +299,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     __shared__ uint32_t s_swv[SWEEP ? W : 1][SWEEP ? DEC_R * 64 + 64 : 1];
     __shared__ __attribute__((aligned(8))) uint2 s_swb[SWEEP ? W : 1][SWEEP ? SWEEP_PX / 32 : 1];   // .x: 32 start bits, .y: the starts in front of them
 
+    SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     uint32_t img = 0, chunk_first = 0, tab_off = 0;   // MODE > 0: the image and the chunk range of this workgroup

@@ -579,6 +579,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // there and began inside the lane, seqoia.h:554-561), 0 where pixel j does not repeat
     __shared__ __attribute__((aligned(8))) uint32_t s_runtab[256][2];
 
+    SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
     const int w = (int)bcast_first(threadIdx.x >> 6);
     const int jid = job_ids[blockIdx.x];

@@ -897,3 +897,75 @@ def test_run_heavy_streams_take_the_position_major_store_path(sq, orc, monkeypat
                 assert bytes(dec.out.reshape(-1).cpu().numpy()) == want.tobytes(), (oc, w, h, shift, knob)
                 assert int(arena[shift + w * h * oc :].max()) == 0 and (shift == 0 or int(arena[:shift].max()) == 0), "wrote outside the image"
                 dec.close()
+
+
+def test_a_relaunched_plan_finds_its_result_rows_reset(sq, orc, route):
+    """No copy resets the result rows in front of a launch: the first kernel that takes a job resets its row itself (sqoa_runtime.hip,
+    plan_enqueue), and a refused job's row is written once when the plan is filled.  So a plan launched AGAIN, over the same buffers
+    with other bytes in them and no plan_update in between, must report what it finds now, whatever the launch before left in the row:
+    a broken header (BADARG) after a good stream, a good SQOA stream after the broken header (status 0, exact length, the pixels),
+    a QOI-compat stream (through SLOWPATH to the QOI-compat kernel) after that, the SQOA stream again; and the rows of jobs the plan
+    refused stay as they were through all of it.  On every route of the `route` fixture (one workgroup per stream in its shapes, three
+    passes)."""
+    import torch
+
+    o = orc.best()
+    w, h, ch = 160, 90, 4
+    px = [orc.synth(w, h, ch, cls, seed=21, img=k) for k, cls in enumerate(["mixed", "icon", "photo", "mixed"])]
+    sqoa = [o.encode(p, w, h, ch, 0) for p in px]
+    qoi = [o.encode(p, w, h, ch, 1) for p in px]
+    slot = max(len(s) for s in sqoa + qoi) + 64
+    buf = torch.zeros((len(px) + 1, slot), dtype=torch.uint8, device="cuda")
+
+    def put(streams):
+        host = np.zeros((len(px) + 1, slot), dtype=np.uint8)
+        for i, s in enumerate(streams):
+            host[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+        buf.copy_(torch.from_numpy(host).cuda())
+        torch.cuda.synchronize()
+
+    # (a job states its stream's exact size: the SQOA and the QOI-compat stream of an image differ in length, so each framing has a plan of its own)
+    items = [(buf[i].data_ptr(), len(sqoa[i]), w, h, 4) for i in range(len(px))] + [(buf[len(px)].data_ptr(), 10, w, h, 4)]   # the last job: a stream shorter than a header
+    dec = sq.DecodeList(items)
+
+    def check(expect_ok, streams):
+        dec.launch()
+        res = dec.results()
+        for i in range(len(px)):
+            if expect_ok[i]:
+                assert res["status"][i] == 0 and res["len"][i] == w * h * 4, (i, res["status"][i], res["len"][i])
+                want = o.decode(streams[i], 4)[0]
+                assert dec.image(i).cpu().numpy().tobytes() == want.tobytes(), i
+            else:
+                assert res["status"][i] != 0 and res["len"][i] == 0, (i, res["status"][i], res["len"][i])
+        assert res["status"][len(px)] != 0 and res["len"][len(px)] == 0   # the refused job's row, untouched by every launch
+
+    put(sqoa)
+    check([True] * 4, sqoa)
+    broken = [bytes([0x51]) + s[1:] if i % 2 == 0 else s for i, s in enumerate(sqoa)]   # a wrong magic in jobs 0 and 2
+    put(broken)
+    check([i % 2 == 1 for i in range(4)], broken)
+    put(sqoa)
+    check([True] * 4, sqoa)
+    # an SQOA_OP_REF in job 1 (handed to the exact decoder: SLOWPATH on the way), then the plain stream again
+    ref = list(sqoa)
+    body = bytearray(ref[1])
+    body[15 + 40] = 0x05
+    ref[1] = bytes(body)
+    if o.decode(ref[1], 4)[0] is not None:
+        put(ref)
+        check([True] * 4, ref)
+        put(sqoa)
+        check([True] * 4, sqoa)
+    dec.close()
+    # the QOI-compat leg: a plan over QOI-compat streams (SLOWPATH in the wave decoder, decoded by the kernel behind it), broken, whole again
+    items = [(buf[i].data_ptr(), len(qoi[i]), w, h, 4) for i in range(len(px))] + [(buf[len(px)].data_ptr(), 10, w, h, 4)]
+    dec = sq.DecodeList(items)
+    put(qoi)
+    check([True] * 4, qoi)
+    broken = [s[:12] + bytes([9]) + s[13:] if i == 3 else s for i, s in enumerate(qoi)]      # channels byte 9 in job 3
+    put(broken)
+    check([i != 3 for i in range(4)], broken)
+    put(qoi)
+    check([True] * 4, qoi)
+    dec.close()

@@ -810,3 +810,29 @@ def test_plans_run_on_the_last_visible_device(sq, orc):
             assert np.array_equal(dec.out[..., :ch].cpu().numpy(), host)
             dec.close()
             enc.close()
+
+
+@pytest.mark.parametrize("strips", ["0", "1"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_a_relaunched_encode_plan_reports_the_new_pixels(sq, orc, monkeypatch, strips, mode):
+    """The encoder resets its result rows itself (thread 0 of an image's workgroup; the first workgroup of the strip pack): a plan
+    launched again over the same pixel buffer with other pixels in it -- no plan_update in between -- reports the new streams' lengths
+    and bytes, per image, as one workgroup per image and as strips cut on the device; and many small images on one wave each."""
+    import torch
+
+    monkeypatch.setenv("SQOA_HIP_STRIPS", strips)
+    o = orc.best()
+    for n, w, h, ch in ((3, 320, 200, 4), (600, 40, 30, 3)):
+        px = torch.empty((n, h, w, ch), dtype=torch.uint8, device="cuda")
+        enc = sq.EncodePlan(px, qoi_compat=mode)
+        for cls, seed in (("mixed", 3), ("icon", 4), ("photo", 5), ("mixed", 3)):
+            sq.synth(px, cls, seed=seed, img0=0)
+            torch.cuda.synchronize()
+            enc.launch()
+            res = enc.results()
+            assert (res["status"] == 0).all()
+            sample = list(range(n)) if n <= 8 else [0, 1, n // 2, n - 1]
+            for k, got in zip(sample, enc.streams(sample)):
+                want = o.encode(orc.synth(w, h, ch, cls, seed, k), w, h, ch, mode)
+                assert int(res["len"][k]) == len(want) and got == want, (cls, k)
+        enc.close()

@@ -18,6 +18,10 @@ rocprofv3 --output-format csv --pmc $SQ1 -d $out/pmc_sq_$tag -o run -- python3 b
 rocprofv3 --output-format csv --pmc $SQ2 -d $out/pmc_sq2_$tag -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-secondary > /dev/null 2>&1
 python3 tools/pmc_table.py "$out/pmc_fetch_$tag/**/*counter_collection.csv" "$out/pmc_write_$tag/**/*counter_collection.csv" "$out/pmc_sq_$tag/**/*counter_collection.csv" "$out/pmc_sq2_$tag/**/*counter_collection.csv" > $out/${tag}_pmc_summary.txt
 find $out/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
+# the kernels' durations by phase of that run (median / p10 of the 20 calls inside the timed steps and of the 20 of the single-kernel loop: the
+# mean of the stats file runs over the spin-up as well); back in the build container: tools/pmc_latest.py gpurun_out/TAG_pmc_summary.txt TAG
+# gpurun_out/TAG_kernel_stats.csv gpurun_out/TAG_kernel_phases.json -> profiles/pmc_hbm_latest.json
+python3 tools/kernel_phases.py $(find $out/prof_$tag -name "*kernel_trace.csv" | head -1) 20 > $out/${tag}_kernel_phases.json
 # workgroup timelines of the two headline kernels (start / end of every workgroup, per compute unit: median / p99 / max end time) -- from the
 # diagnostic build, when the snapshot carries one (tools/mkvariant.sh trace "-DSQOA_TRACE" in the build container; its times are the
 # instrumented build's, ~40 % / 15 % longer than the product's: read the SHAPE of the distribution)
