@@ -128,9 +128,21 @@ SQOA_DEV NbrPx sload_px(unsigned long long addr, int ch, uint32_t orv) {
     return NbrPx{*(kcptr32)(addr & ~3ull), *(kcptr32)((addr + (unsigned)ch - 1u) & ~3ull), ((uint32_t)addr & 3u) * 8u, orv};
 }
 typedef __attribute__((address_space(3))) void* lds_ptr;
+// The encoder's pointers into its own LDS buffers (staging, landing) are LDS pointers, 32 bits each, not generic ones: a generic pointer is an
+// SGPR pair, and every use of it as an LDS address a null test and a select -- in a kernel that spills SGPRs (98 -> 63 with these).
+typedef __attribute__((address_space(3))) uint8_t* lptr8;
+typedef const __attribute__((address_space(3))) uint8_t* lcptr8;
+typedef __attribute__((address_space(3))) uint32_t* lptr32;
+typedef __attribute__((address_space(3))) u32x4* lptr_x4;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2* lptr_x2;
+typedef uint32_t u32_una1 __attribute__((aligned(1)));
+typedef u32x4 u32x4_una1 __attribute__((aligned(1)));
+typedef __attribute__((address_space(3))) u32_una1* lptr32u;
+typedef __attribute__((address_space(3))) u32x4_una1* lptr_x4u;
 
 // Copy T staged bytes to global memory at g (any alignment) and clear the staging area.
-SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) {
+SQOA_DEV void flush_stage(lptr8 stage, uint32_t T, gptr8 g, int lane_unused) {
     // The lane number, recomputed here and opaque to the compiler: with the caller's `lane` the per-lane LDS addresses below are
     // loop invariants, which at 64 VGPRs get SPILLED -- and every reload is a scratch_load + s_waitcnt vmcnt(0) in the middle of
     // the flush, i.e. a wait for the 16-byte stores issued just before it (the flush's pieces went out one store latency apart).
@@ -144,12 +156,12 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) 
     const uint32_t nb = (T - a) >> 4;
     for (uint32_t u = lane; u < nb; u += 64) {
         u32x4 v;
-        __builtin_memcpy(&v, stage + a + 16u * u, 16);  // unaligned LDS read
+        v = *(lptr_x4u)(stage + a + 16u * u);  // unaligned LDS read
         *(gptr128)(g + a + 16u * u) = v;
     }
     const uint32_t t0 = a + 16u * nb;
     if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
-    for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16u; i < T + 12u; i += 1024u) *(lptr_x4)(stage + i) = u32x4{0u, 0u, 0u, 0u};
 #else
     // 16-byte pieces: aligned LDS reads, global stores at whatever alignment the stream position has (unaligned vector
     // stores cost nothing measurable here; the lines are completed in L2 by the neighbouring sub-tiles' flushes); the last
@@ -157,13 +169,13 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) 
     typedef u32x4 u32x4_una __attribute__((aligned(1)));
     typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
     const uint32_t nb = T >> 4;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
     if (nb <= 64u) {  // run-heavy content: at most one piece per lane
         if ((uint32_t)lane < nb) {
 #ifndef SQOA_DBG_NOSTORE
-            ((gptr128u)g)[lane] = *reinterpret_cast<const u32x4*>(stage + 16u * lane);
+            ((gptr128u)g)[lane] = *(lptr_x4)(stage + 16u * lane);
 #endif
-            *reinterpret_cast<uint4*>(stage + 16u * lane) = zero;
+            *(lptr_x4)(stage + 16u * lane) = zero;
         }
     } else
 #pragma unroll
@@ -171,18 +183,18 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) 
         const uint32_t u = (uint32_t)lane + 64u * k;
         if (u < nb) {
 #ifdef SQOA_DBG_NOSTORE
-            u32x4 vv = *reinterpret_cast<const u32x4*>(stage + 16u * u);
+            u32x4 vv = *(lptr_x4)(stage + 16u * u);
             asm volatile("" :: "v"(vv), "v"(g));
 #else
-            ((gptr128u)g)[u] = *reinterpret_cast<const u32x4*>(stage + 16u * u);
+            ((gptr128u)g)[u] = *(lptr_x4)(stage + 16u * u);
 #endif
-            *reinterpret_cast<uint4*>(stage + 16u * u) = zero;
+            *(lptr_x4)(stage + 16u * u) = zero;
         }
     }
     const uint32_t t0 = nb << 4;
     if ((uint32_t)lane < T - t0) g[t0 + lane] = stage[t0 + lane];
     // the partial piece and the 12 bytes of OR window behind it
-    if (lane < 2) *reinterpret_cast<uint4*>(stage + t0 + 16u * lane) = zero;
+    if (lane < 2) *(lptr_x4)(stage + t0 + 16u * lane) = zero;
 #endif
 }
 
@@ -194,8 +206,8 @@ SQOA_DEV void flush_stage(uint8_t* stage, uint32_t T, gptr8 g, int lane_unused) 
 // sub-tile.  The one place that reads the landing buffer (take / take8) does its own s_waitcnt vmcnt(0).  (2) The per-lane source
 // address was a loop invariant that got spilled; its reload (scratch_load + vmcnt(0)) in front of the loads drained the stores of the
 // flush just before.  Here the address is an SGPR base + 16 * lane, the lane number recomputed on the spot.
-SQOA_DEV void lds_dma(unsigned long long gaddr, uint8_t* lds_dst, bool half_second) {
-    const uint32_t lds_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_dst);
+SQOA_DEV void lds_dma(unsigned long long gaddr, lptr8 lds_dst, bool half_second) {
+    const uint32_t lds_addr = bcast_first((uint32_t)(uintptr_t)lds_dst);
     uint32_t keep, off;
     if (!half_second) {
         asm volatile(
@@ -421,10 +433,10 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
 // Phase B: run bytes, byte offsets (two DPP prefix sums per four rows) and staging into LDS.
 template <bool QOI>
 SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
-                            uint32_t pa, bool has_after, bool eof, uint8_t* stage, int lane, unsigned long long le_mask, uint32_t* tabw,
+                            uint32_t pa, bool has_after, bool eof, lptr8 stage, int lane, unsigned long long le_mask, uint32_t* tabw,
                             unsigned long long* smask) {
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
-    const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
+    const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)stage);
     const uint32_t sink_addr = stage_addr + 4u * lane;  // a pixel that emits nothing ORs its zeros into a dword of the lane's own, anywhere in the buffer
     uint32_t cr[ENC_S + 1];  // pixels repeating their predecessor immediately before each row
     cr[0] = c_in;
@@ -604,10 +616,10 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const uint32_t nsub = (N + ENC_SUB - 1) / ENC_SUB;
     constexpr uint32_t M = QOI ? 62u : 512u;  // seqoia.h:411-412
 
-    uint8_t* stage = s_stage[w];
+    const lptr8 stage = (lptr8)s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QW][lane] = 0; }
-    for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *reinterpret_cast<uint4*>(stage + i) = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *(lptr_x4)(stage + i) = u32x4{0u, 0u, 0u, 0u};
     {
         for (uint32_t e8 = threadIdx.x; e8 < 256u; e8 += W * 64) {
             unsigned long long v = 0;
@@ -648,8 +660,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
     uint32_t cur[ENC_S], cur_pb = kPxInit, cur_pa = 0;  // cur_pb / cur_pa: the pixels before / after the sub-tile (wave-uniform)
     bool cur_raw3 = false;
-    uint8_t* pre = s_pre[w];                       // where the next sub-tile lands
-    uint8_t* held = s_pre[QL8 ? W + w : w];        // QOI-compat: the buffer the current sub-tile's pixels were taken from
+    lptr8 pre = (lptr8)s_pre[w];                   // where the next sub-tile lands
+    lptr8 held = (lptr8)s_pre[QL8 ? W + w : w];    // QOI-compat: the buffer the current sub-tile's pixels were taken from
     // The pixels of a wave's NEXT sub-tile travel global -> LDS directly (global_load_lds_dwordx4, any source alignment:
     // tools/ubench/lds_dma_align.hip), two instructions per 512 pixels, and are picked up into VGPRs only when the current
     // sub-tile's have been consumed: nothing is held in registers across a sub-tile, which is what lets four images share a CU
@@ -698,11 +710,11 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             pb = NbrPx{bcast_first(base ? load_px(src, base - 1, ch) : (sflags & SQOA_HIP_JOB_PREV) ? load_px(src - ch, 0, ch) : kPxInit), 0u, 0u, 0u};
             pa = NbrPx{bcast_first(base + ENC_SUB < N ? load_px(src, base + ENC_SUB, ch) : 0u), 0u, 0u, 0u};
 #pragma unroll
-            for (int s = 0; s < ENC_S; ++s) reinterpret_cast<uint32_t*>(pre)[s * 64 + lane] = px[s];
+            for (int s = 0; s < ENC_S; ++s) ((lptr32)pre)[s * 64 + lane] = px[s];
         }
     };
     // (QOI-compat: the buffer just taken from becomes `held` -- it keeps the sub-tile readable -- and the other one the landing buffer)
-    auto swap_buffers = [&]() { if constexpr (QL8) { uint8_t* t = held; held = pre; pre = t; } };
+    auto swap_buffers = [&]() { if constexpr (QL8) { lptr8 t = held; held = pre; pre = t; } };
     auto take = [&](uint32_t (&px)[ENC_S], bool raw3) {
         // the compiler does not order LDS reads behind LDS-DMA loads by itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -710,12 +722,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) {
                 uint32_t v;
-                __builtin_memcpy(&v, pre + 3 * (s * 64 + lane), 4);  // unaligned LDS read; the 4th byte is the next pixel's
+                v = *(lptr32u)(pre + 3 * (s * 64 + lane));  // unaligned LDS read; the 4th byte is the next pixel's
                 px[s] = v | 0xff000000u;
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < ENC_S; ++s) px[s] = reinterpret_cast<const uint32_t*>(pre)[s * 64 + lane];
+            for (int s = 0; s < ENC_S; ++s) px[s] = ((lptr32)pre)[s * 64 + lane];
         }
         swap_buffers();
     };
@@ -725,8 +737,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     auto take8 = [&](uint32_t (&px)[ENC_S], bool raw3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (raw3) {
-            const uint2 a = *reinterpret_cast<const uint2*>(pre + 24 * lane), b = *reinterpret_cast<const uint2*>(pre + 24 * lane + 8),
-                        c = *reinterpret_cast<const uint2*>(pre + 24 * lane + 16);
+            const u32x2 a = *(lptr_x2)(pre + 24 * lane), b = *(lptr_x2)(pre + 24 * lane + 8),
+                        c = *(lptr_x2)(pre + 24 * lane + 16);
             if constexpr (QOI) {
                 // QOI-compat: the index probe reads the sub-tile once more, row by row (body8) -- 3-byte pixels would be 8 unaligned LDS
                 // reads per lane there, which stall the LDS pipe (4096 x 512 x 512 RGB icons 4.35 ms against 3.01 ms as RGBA).  The lane's
@@ -735,13 +747,13 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 auto rgb = [](uint32_t x) { return (x & 0x00ffffffu) | 0xff000000u; };
                 px[0] = rgb(a.x); px[1] = rgb(__builtin_amdgcn_alignbyte(a.y, a.x, 3)); px[2] = rgb(__builtin_amdgcn_alignbyte(b.x, a.y, 2)); px[3] = rgb(b.x >> 8);
                 px[4] = rgb(b.y); px[5] = rgb(__builtin_amdgcn_alignbyte(c.x, b.y, 3)); px[6] = rgb(__builtin_amdgcn_alignbyte(c.y, c.x, 2)); px[7] = rgb(c.y >> 8);
-                *reinterpret_cast<u32x4*>(pre + 32 * lane) = u32x4{px[0], px[1], px[2], px[3]};
-                *reinterpret_cast<u32x4*>(pre + 32 * lane + 16) = u32x4{px[4], px[5], px[6], px[7]};
+                *(lptr_x4)(pre + 32 * lane) = u32x4{px[0], px[1], px[2], px[3]};
+                *(lptr_x4)(pre + 32 * lane + 16) = u32x4{px[4], px[5], px[6], px[7]};
             } else {
                 px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y; px[6] = 0; px[7] = 0;
             }
         } else {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(pre + 32 * lane), b = *reinterpret_cast<const u32x4*>(pre + 32 * lane + 16);
+            const u32x4 a = *(lptr_x4)(pre + 32 * lane), b = *(lptr_x4)(pre + 32 * lane + 16);
             px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
         }
         swap_buffers();
@@ -907,9 +919,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 }
             }
             if (lane == 0) {  // position-independent staging: the bytes start at offset 0 of the (zeroed) buffer
-                reinterpret_cast<uint32_t*>(stage)[0] = (uint32_t)v;
-                reinterpret_cast<uint32_t*>(stage)[1] = (uint32_t)(v >> 32);
-                reinterpret_cast<uint32_t*>(stage)[2] = b9;
+                ((lptr32)stage)[0] = (uint32_t)v;
+                ((lptr32)stage)[1] = (uint32_t)(v >> 32);
+                ((lptr32)stage)[2] = b9;
             }
             sbase = nbytes;
         } else if (swar) {
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
             const uint32_t sh = (o & 3u) * 8u;
             const unsigned long long v = ((unsigned long long)hi << 32 | lo) << sh;
-            uint32_t* p = reinterpret_cast<uint32_t*>(stage + (o & ~3u));
+            lptr32 p = (lptr32)(stage + (o & ~3u));
             if (n) {
                 __hip_atomic_fetch_or(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(p + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 if (spill) __hip_atomic_fetch_or(p + 2, hi >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (n == 9u) {
                     const uint32_t o9 = o + 8u;
-                    __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stage + (o9 & ~3u)), b9 << ((o9 & 3u) * 8u),
+                    __hip_atomic_fetch_or((lptr32)(stage + (o9 & ~3u)), b9 << ((o9 & 3u) * 8u),
                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
@@ -1094,9 +1106,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 nbytes = q + 2u;
             }
             if (lane == 0) {
-                reinterpret_cast<uint32_t*>(stage)[0] = (uint32_t)v;
-                reinterpret_cast<uint32_t*>(stage)[1] = (uint32_t)(v >> 32);
-                reinterpret_cast<uint32_t*>(stage)[2] = b9;
+                ((lptr32)stage)[0] = (uint32_t)v;
+                ((lptr32)stage)[1] = (uint32_t)(v >> 32);
+                ((lptr32)stage)[2] = b9;
             }
             sbase = nbytes;
         } else {
@@ -1157,8 +1169,8 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 #pragma unroll
                     for (int r = 0; r < ENC_S; ++r) {
                         uint32_t v;
-                        if constexpr (PX3) { __builtin_memcpy(&v, held + 3 * (r * 64 + lane), 4); v |= 0xff000000u; }
-                        else v = reinterpret_cast<const uint32_t*>(held)[r * 64 + lane];
+                        if constexpr (PX3) { v = *(lptr32u)(held + 3 * (r * 64 + lane)); v |= 0xff000000u; }
+                        else v = ((lptr32)held)[r * 64 + lane];
                         rowpx[r] = v;
                         nebits |= (v != shift_up1(v, carry) ? 1u : 0u) << r;
                         carry = bcast_lane(v, 63);
@@ -1289,7 +1301,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             const uint32_t T0 = P0 >> 24, T = T0 + (P1 >> 24);
             const uint32_t incl = wave_incl_scan(T);
             sbase = bcast_lane(incl, 63);
-            const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)stage);
+            const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)stage);
             // a lane without bytes ORs its zeros into a dword of its own (no 64 lanes on one LDS word in flat stretches)
             const uint32_t lb0 = T ? stage_addr + incl - T : stage_addr + 4u * lane, lb1 = lb0 + T0;
             const uint32_t X0 = P0 - Nn0, X1 = P1 - Nn1;   // exclusive prefixes, one byte per pixel

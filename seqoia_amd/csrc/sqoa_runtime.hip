@@ -19,7 +19,7 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int wave_only, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size, int lb);
@@ -114,6 +114,8 @@ struct sqoa_hip_plan {
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int shape = 0;                      // decode, the streams that get a workgroup each: the wave decoder's shape (sqoa_launch_decode_wave) -- bit 0 = many short
                                         // streams, bit 1 = 12 stream bytes per lane, bit 2 = position-major stores
+    int n_chain_b = 0, shape_b = 0;     // decode: the last n_chain_b of the streams that get a workgroup each are launched apart, with a shape of their own
+                                        // (a plan of mixed output formats: its four-channel streams take the balanced kernel, the others what suits them)
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256, 8};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
@@ -445,6 +447,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             const char* kw = getenv("SQOA_HIP_DEC_WIDE");
             const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
             const char* kb = getenv("SQOA_HIP_DEC_BAL");
+            auto four = [&](int i) { return jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull); };   // what the balanced kernel takes
             auto shape_of = [&](size_t a, size_t b) -> int {
                 if (a >= b) return 0;
                 unsigned long long by = 0, by4 = 0, px = 0;
@@ -454,7 +457,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                     by += j.src_size;
                     px += (unsigned long long)j.desc.width * j.desc.height;
                     if (j.desc.channels == 4) by4 += j.src_size;
-                    if (j.desc.channels != 4 || (j.dst & 3ull)) all4 = false;
+                    if (!four(ids_a[k])) all4 = false;
                     if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
                 }
                 const bool roomy = by / (b - a) >= (12u << 10);
@@ -463,13 +466,42 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
                 //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
                 //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
-                //    -- a kernel for four channels to dword-aligned addresses only, so only for plans whose every job is that
+                //    -- a kernel for four channels to dword-aligned addresses only, so only for lists whose every job is that
                 int bal = wide && !sweep && !p->small;
                 if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
                 bal = bal && all4;
                 return p->small | wide << 1 | sweep << 2 | bal << 3;
             };
             p->shape = shape_of(c0, ids_a.size());
+            p->n_chain_b = 0; p->shape_b = 0;
+            // A list of mixed output formats (BASELINE configs[4]: 557 RGB photos to three channels among 7 635 RGBA images): the balanced kernel
+            // is 12 % faster on the four-channel streams, which are most of such a list -- they go first, in a launch of their own, and the
+            // others behind them with the shape that suits THEM, on a side stream so that the two launches share the chip (one behind the
+            // other on one stream, the second launch's few long streams would have the chip to themselves: measured in round 4, lost).
+            // Where the four-channel streams are less than half of the bytes, or would not take the balanced kernel alone: one launch as before.
+            // (SQOA_HIP_DEC_SPLIT = 0 / 1 forces it.)
+            if (!(p->shape & 8) && ids_a.size() - c0 >= 2) {
+                std::vector<int> a4, rest;
+                unsigned long long by4 = 0, by = 0;
+                for (size_t k = c0; k < ids_a.size(); ++k) {
+                    (four(ids_a[k]) ? a4 : rest).push_back(ids_a[k]);
+                    by += jobs[ids_a[k]].src_size;
+                    if (four(ids_a[k])) by4 += jobs[ids_a[k]].src_size;
+                }
+                int split = !a4.empty() && !rest.empty() && 2 * by4 >= by;
+                if (const char* kp = getenv("SQOA_HIP_DEC_SPLIT")) split = kp[0] == '1' ? (!a4.empty() && !rest.empty()) : kp[0] == '0' ? 0 : split;
+                if (split) {
+                    std::vector<int> keep(ids_a.begin() + (long)c0, ids_a.end());
+                    std::copy(a4.begin(), a4.end(), ids_a.begin() + (long)c0);            // (both halves keep the largest-first order)
+                    std::copy(rest.begin(), rest.end(), ids_a.begin() + (long)(c0 + a4.size()));
+                    const int sa = shape_of(c0, c0 + a4.size());
+                    if (sa & 8) {
+                        p->shape = sa;
+                        p->shape_b = shape_of(c0 + a4.size(), ids_a.size());
+                        p->n_chain_b = (int)rest.size();
+                    } else std::copy(keep.begin(), keep.end(), ids_a.begin() + (long)c0);   // (the four-channel streams alone would not take it either)
+                }
+            }
         }
     }
     p->n = n;
@@ -668,7 +700,7 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }

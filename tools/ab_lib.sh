@@ -3,6 +3,7 @@
 # rounds on one box; every line printed, then per variant median / min / max of the ms per launch and the band (max - min) / median.
 # A variant name may be a family: NAME@ stands for NAME_p0 NAME_p8 NAME_p16 (the same source at three code placements, tools/mkplaced.sh),
 # reported both per placement and pooled -- a difference between two families counts only where it exceeds the placement band.
+set -o pipefail
 vs=$1; rounds=${2:-6}; what=${3:-decode}; shift 3
 list=""
 for v in $vs; do case $v in *@) b=${v%@}; list="$list ${b}_p0 ${b}_p8 ${b}_p16";; *) list="$list $v";; esac; done
