@@ -537,8 +537,9 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // `shape`: the wave decoder's shape for the streams that get a workgroup each -- bit 0 = many short streams, bit 1 = twelve stream bytes per
 // lane, bit 2 = the position-major store path (sqoa_launch_decode_wave; the plan decides, sqoa_runtime.hip)
 // `n_b`, `shape_b`: the last n_b of the streams that get a workgroup each are launched apart from the others, with a shape of their own (the plan
-// splits lists of mixed output formats: sqoa_runtime.hip)
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int wave_only, const sqoa_dp_tables* dp,
+// splits lists of mixed output formats: sqoa_runtime.hip) -- here, behind the others, or (`b_launched`) by the caller on a side stream, whose
+// `join_event` this stream waits for before the kernels that look at every job's status
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int small = shape & 1;
@@ -558,7 +559,9 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (e != hipSuccess) return e;
     e = sqoa_launch_decode_wave(d_jobs, d_ids + n_multi, n - n_multi - n_b, shape, d_results, stream);
     if (e != hipSuccess) return e;
-    if (n_b > 0) e = sqoa_launch_decode_wave(d_jobs, d_ids + n - n_b, n_b, shape_b, d_results, stream);
+    if (n_b > 0 && !b_launched) e = sqoa_launch_decode_wave(d_jobs, d_ids + n - n_b, n_b, shape_b, d_results, stream);
+    if (e != hipSuccess) return e;
+    if (n_b > 0 && b_launched && join_event) e = hipStreamWaitEvent(stream, (hipEvent_t)join_event, 0);
     if (e != hipSuccess) return e;
     if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
 #if !defined(SQOA_QDEC) || SQOA_QDEC

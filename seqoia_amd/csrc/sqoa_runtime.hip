@@ -19,7 +19,8 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, int cus, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int wave_only, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size, int lb);
@@ -125,6 +126,8 @@ struct sqoa_hip_plan {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;       // recorded behind the kernels of the most recent launch, on whatever stream it used
+    hipStream_t side = nullptr;         // decode plans that launch a part of their streams apart (n_chain_b): that part runs here, forked from and joined to the launch's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool pending = false;               // ev_done has been recorded since the last wait
 };
 
@@ -646,7 +649,9 @@ int sqoa_hip_plan_create(int device, int kind, const sqoa_hip_job* jobs, int n, 
         (e = hipMalloc((void**)&p->d_ids, sizeof(int) * (size_t)(n ? n : 1))) != hipSuccess ||
         (e = hipMalloc((void**)&p->d_word, 256)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&p->ev0)) != hipSuccess ||
-        (e = hipEventCreate(&p->ev1)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreate(&p->ev1)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming)) != hipSuccess ||
+        (kind == SQOA_HIP_DECODE && ((e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking)) != hipSuccess ||
+                                     (e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)) != hipSuccess))) {
         sqoa_hip_plan_destroy(p);
         return fail(SQOA_HIP_ENOMEM, "sqoa_hip_plan_create: allocation", e);
     }
@@ -668,6 +673,9 @@ void sqoa_hip_plan_destroy(sqoa_hip_plan* p) {
     hipSetDevice(p->device);
     if (p->stream) plan_wait(p);
     if (p->ev_done) hipEventDestroy(p->ev_done);
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
+    if (p->side) hipStreamDestroy(p->side);
     if (p->d_jobs) hipFree(p->d_jobs);
     if (p->d_results) hipFree(p->d_results);
     if (p->d_word) hipFree(p->d_word);
@@ -700,7 +708,18 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
         HIP_TRY(sqoa_launch_encode(p->d_jobs, idb + p->n_cut_qoi, p->n_qoi - p->n_cut_qoi - p->n_qoi_small, 1, p->d_results, p->cus, s), SQOA_HIP_ELAUNCH);
         HIP_TRY(sqoa_launch_encode_small(p->d_jobs, idb + p->n_qoi - p->n_qoi_small, p->n_qoi_small, 1, p->d_results, s), SQOA_HIP_ELAUNCH);
     } else {
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, p->wave_only, &p->dp, p->d_results, s), SQOA_HIP_ELAUNCH);
+        // The part of the streams that is launched apart (a list of mixed output formats: plan_fill) goes to the side stream, forked off in
+        // front of everything and joined behind the wave decoders: its few hundred workgroups share the chip with the others' instead of
+        // following them (an event fork / join: capturable into a graph like the rest of a launch).
+        const bool fork = p->n_chain_b > 0 && p->side;
+        if (fork) {
+            HIP_TRY(hipEventRecord(p->ev_fork, s), SQOA_HIP_ELAUNCH);
+            HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0), SQOA_HIP_ELAUNCH);
+            HIP_TRY(sqoa_launch_decode_wave(p->d_jobs, p->d_ids + p->n_sqoa - p->n_chain_b, p->n_chain_b, p->shape_b, p->d_results, p->side), SQOA_HIP_ELAUNCH);
+            HIP_TRY(hipEventRecord(p->ev_join, p->side), SQOA_HIP_ELAUNCH);
+        }
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, fork ? 1 : 0, fork ? (void*)p->ev_join : nullptr, p->wave_only, &p->dp,
+                                   p->d_results, s), SQOA_HIP_ELAUNCH);
     }
     return 0;
 }

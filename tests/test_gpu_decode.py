@@ -969,3 +969,59 @@ def test_a_relaunched_plan_finds_its_result_rows_reset(sq, orc, route):
     put(qoi)
     check([True] * 4, qoi)
     dec.close()
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_a_plan_of_mixed_output_formats_splits_its_launches(sq, orc, monkeypatch, split):
+    """A decode plan whose jobs go to different output formats (BASELINE configs[4]: RGB photos to three channels among RGBA images to
+    four): the four-channel streams go to the balanced kernel in a launch of their own, the others run beside them on the plan's side
+    stream (forked from and joined to the launch's stream) -- every image as the compiled reference decodes it, launched directly, launched
+    again, and replayed from a HIP graph (the fork / join is part of the capture); SQOA_HIP_DEC_SPLIT=0 is the single launch."""
+    import torch
+
+    monkeypatch.setenv("SQOA_HIP_DEC_SPLIT", split)
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", "0")
+    o = orc.best()
+    imgs = []
+    for k in range(40):
+        ch = 3 if k % 5 == 0 else 4
+        w, h = (300, 200) if k % 3 else (220, 160)
+        cls = ["mixed", "photo", "icon"][k % 3]
+        imgs.append((w, h, ch, orc.synth(w, h, ch, cls, seed=9, img=k)))
+    streams = [o.encode(px, w, h, ch, 0) for (w, h, ch, px) in imgs]
+    slot = max(len(s) for s in streams) + 64
+    host = np.zeros((len(streams), slot), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        host[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    buf = torch.from_numpy(host).cuda()
+    items = [(buf[i].data_ptr(), len(streams[i]), w, h, ch) for i, (w, h, ch, _) in enumerate(imgs)]
+    dec = sq.DecodeList(items)
+
+    def check():
+        res = dec.results()
+        assert (res["status"] == 0).all()
+        for i, (w, h, ch, px) in enumerate(imgs):
+            assert dec.image(i).cpu().numpy().tobytes() == px.tobytes(), i
+
+    dec.launch()
+    check()
+    dec.out.zero_()
+    torch.cuda.synchronize()
+    dec.launch()
+    check()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dec.launch(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        dec.launch(side.cuda_stream)
+    for _ in range(2):
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        check()
+    dec.close()
