@@ -70,7 +70,8 @@ typedef struct {
 #define SQOA_HIP_ST_BADARG    1  /* the reference would return NULL (seqoia.h:465-480, :662-688, :705-707) */
 #define SQOA_HIP_ST_OVERFLOW  2  /* dst_cap too small */
 #define SQOA_HIP_ST_INTERNAL  3  /* chain wait timed out: a bug, never expected */
-#define SQOA_HIP_ST_SLOWPATH  4  /* decode: stream needs another kernel (REF op etc.); handled inside the launch, seen by callers only for SQOA_HIP_JOB_WAVEONLY jobs */
+#define SQOA_HIP_ST_SLOWPATH  4  /* decode: stream needs another kernel (REF op etc.); handled inside the launch -- or, for a plan whose earlier launches
+                                  * never needed those kernels, inside sqoa_hip_plan_results (below) --, seen by callers only for SQOA_HIP_JOB_WAVEONLY jobs */
 
 enum { SQOA_HIP_ENCODE = 0, SQOA_HIP_DECODE = 1 };
 
@@ -151,7 +152,14 @@ void *sqoa_hip_plan_stream(sqoa_hip_plan *plan);
  * stream).  Asynchronous; no allocation, no host sync: graph-capturable. */
 int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 
-/* Wait for the plan's stream and copy the n results to host memory. */
+/* Wait for the plan's most recent launch and copy the n results to host memory.  This call is what makes a launch's statuses and
+ * lengths FINAL: a decode plan launches two more kernels behind its wave decoder (QOI-compat streams, mono streams, 1- / 2-channel
+ * output, SQOA_OP_REF) until a launch's rows, read here in full (n = all jobs), show that no job needed them; from then on a launch
+ * leaves them out (two launches, ~9 us: a fifth of a plan of 4096 small icons), and if a later launch's rows come back
+ * SQOA_HIP_ST_SLOWPATH -- other streams in the same buffers --, this call runs the two kernels before it returns the rows.  A caller
+ * that consumes a decode plan's pixels on its own stream without asking for the results (graph replay) sees, for such a stream,
+ * what it would see for any failed job: pixels that are not there yet.  SQOA_HIP_DEC_LAZY=0 in the environment: the two kernels
+ * with every launch. */
 int sqoa_hip_plan_results(sqoa_hip_plan *plan, sqoa_hip_result *out, int n);
 
 /* One-shot forms of the batch extension SURVEY.md section 8(b) asks for ("sqoa_encode_batch / sqoa_decode_batch": an

@@ -89,6 +89,11 @@ typedef const __attribute__((address_space(1))) u32x4* gcptr128;
 constexpr uint32_t kPxInit = 0xff000000u;  // (0,0,0,255): reference seqoia.h:521-525, :716-719
 constexpr int kHeader = 14;                // reference seqoia.h:425
 
+// The unused fourth byte behind sqoa_desc's three flags in a result row: 1 = one of the kernels BEHIND the wave decoder took this job in the
+// launch that wrote the row (reset by the wave decoder with the row).  The plan reads it with the rows: a decode plan none of whose jobs needed
+// those kernels does not launch them the next time (sqoa_runtime.hip, sqoa_hip_plan_results).
+SQOA_DEV void row_mark_standby(sqoa_hip_result* res, uint8_t v) { reinterpret_cast<volatile uint8_t*>(&res->desc)[11] = v; }
+
 SQOA_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // DPP controls (GFX9 encodings)

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
     if (only_slowpath && __builtin_amdgcn_readfirstlane(res->status) != SQOA_HIP_ST_SLOWPATH) return;  // only what the wave-parallel kernel declined: one scalar load otherwise
     const sqoa_hip_job job = jobs[jid];
     __syncthreads();                                                    // every lane has read the status
-    if (only_slowpath && threadIdx.x == 0) res->status = SQOA_HIP_ST_OK;
+    if (only_slowpath && threadIdx.x == 0) { res->status = SQOA_HIP_ST_OK; row_mark_standby(res, 1); }
 
     const Hdr h = parse_header((gcptr8)job.src, res, threadIdx.x == 0);
     const bool shape_ok = (job.desc.width == 0 || job.desc.width == h.width) && (job.desc.height == 0 || job.desc.height == h.height);
@@ -531,6 +531,19 @@ extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sq
 extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                 const void* d_wgs, int n_wgs, void* d_tab, void* d_flags, unsigned per, int scans, int lb, hipStream_t stream);
 
+// The kernels behind the wave decoder, over every job of the plan: what it marked SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat
+// kernel (colour streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel; a
+// job that is not marked costs each of them one scalar load.
+extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+#if !defined(SQOA_QDEC) || SQOA_QDEC
+    hipError_t e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
+    if (e != hipSuccess) return e;
+#endif
+    hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(128), 0, stream, d_jobs, d_ids, d_results, 1);
+    return hipGetLastError();
+}
+
 // Wave-parallel SQOA kernel first (the first `n_multi` ids: few large streams, decoded in three chip-wide passes; the others:
 // one workgroup per stream); what it marks SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat kernel (colour
 // streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel.
@@ -564,10 +577,5 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n_b > 0 && b_launched && join_event) e = hipStreamWaitEvent(stream, (hipEvent_t)join_event, 0);
     if (e != hipSuccess) return e;
     if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
-#if !defined(SQOA_QDEC) || SQOA_QDEC
-    e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
-    if (e != hipSuccess) return e;
-#endif
-    hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(128), 0, stream, d_jobs, d_ids, d_results, 1);
-    return hipGetLastError();
+    return sqoa_launch_decode_standby(d_jobs, d_ids, n, small, d_results, stream);
 }

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (__builtin_amdgcn_readfirstlane(res->status) != SQOA_HIP_ST_SLOWPATH) return;
     const sqoa_hip_job job = jobs[jid];
     gcptr8 src0 = (gcptr8)job.src;
+    if (!SPEC && threadIdx.x == 0) row_mark_standby(res, 1);   // (a job the wave decoder handed on: the plan keeps launching the kernels behind it)
 
     // Only what the SQOA kernel handed on (SQOA_HIP_ST_SLOWPATH: header valid, destination large enough) and only QOI-compat
     // colour streams to 3 or 4 channels; the rest stays marked for decode_fallback_kernel.

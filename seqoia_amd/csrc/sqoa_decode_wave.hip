@@ -388,6 +388,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         res->len = 0; res->status = SQOA_HIP_ST_OK;   // the row as every launch must find it: nobody else has touched it yet (sqoa_runtime.hip, plan_enqueue)
         res->desc.width = hw; res->desc.height = hh; res->desc.channels = (uint8_t)hc;
         res->desc.colorspace = (uint8_t)hs; res->desc.qoi_compat = (uint8_t)q;
+        row_mark_standby(res, 0);
         const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
                           (magic == 0x716f6966u && !q) || hh >= 400000000u / hw);
         uint32_t path = 1;

@@ -20,6 +20,7 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
@@ -40,6 +41,12 @@ extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const 
 #endif
 #ifndef SQOA_DP_SOLO
 #define SQOA_DP_SOLO (550.0 * 1.25)   // R / r, x 1.25: a stream that shares its CU with other streams is slower than alone
+#endif
+// ... and where the others will take the balanced kernel (sqoa_decode_bal.hip; round 5: 1024 streams of 1 Mpixel 2.59 ms chained, 5.96 in
+// three passes; 256 streams, one per compute unit, 1.37 against 1.56): the passes cost 2.3 x, a lone stream 2.3 x 256 x 1.37 / 1.56
+#ifndef SQOA_DP_COST_BAL
+#define SQOA_DP_COST_BAL 2.3
+#define SQOA_DP_SOLO_BAL 520.0
 #endif
 // The same for the encoder (sqoa_strips.hip): an image alone runs at r = 1.8 Mpixel / ms, the chip at R = 670 Mpixel / ms;
 // cut into strips an image costs 1.8 x as much of the chip's time (the cut search, a prologue per strip, one more copy of the
@@ -117,6 +124,10 @@ struct sqoa_hip_plan {
                                         // streams, bit 1 = 12 stream bytes per lane, bit 2 = position-major stores
     int n_chain_b = 0, shape_b = 0;     // decode: the last n_chain_b of the streams that get a workgroup each are launched apart, with a shape of their own
                                         // (a plan of mixed output formats: its four-channel streams take the balanced kernel, the others what suits them)
+    // decode, the two kernels behind the wave decoder (QOI-compat / mono / 1-2 channels / SQOA_OP_REF): launched with every launch until a launch's
+    // result rows -- read by sqoa_hip_plan_results -- say that no job needed them; from then on left out, and sqoa_hip_plan_results runs them itself
+    // for a launch whose rows come back SLOWPATH after all (the streams in the buffers have changed)
+    bool lazy_skip = false, skipped_last = false, launched = false;
     int wave_only = 0;                  // decode: every job carries SQOA_HIP_JOB_WAVEONLY -- the kernels behind the SQOA wave decoder are not launched
     sqoa_dp_tables dp = {nullptr, 0, nullptr, 0, 16, nullptr, nullptr, nullptr, 1, 256, 8};   // decode: the few large streams that take the three-pass route
     size_t dp_images_cap = 0, dp_flags_cap = 0, dp_wgs_cap = 0, dp_tab_cap = 0, dp_qstate_cap = 0;   // allocated rows
@@ -255,7 +266,13 @@ static void snake(std::vector<int>& v, size_t first, int cus, size_t last = (siz
 // Dispatch order of a decode plan's streams and the route each takes: pure host arithmetic, no device needed.
 // order[0 .. *n_multipass) = the streams decoded in three chip-wide passes (largest first), order[*n_multipass .. n) = the ones
 // that get a workgroup each.  `mode`: 0 = the cost model above, -1 = no stream multi-pass, 1 = every stream.
+static int decode_route(const unsigned int* src_sizes, int n, int cus, int mode, double dp_cost, double dp_solo, int* order, int* n_multipass);
 int sqoa_hip_decode_route(const unsigned int* src_sizes, int n, int cus, int mode, int* order, int* n_multipass) {
+    return decode_route(src_sizes, n, cus, mode, SQOA_DP_COST, SQOA_DP_SOLO, order, n_multipass);
+}
+// (`dp_cost`, `dp_solo`: the model's two constants -- the passes' cost per stream byte and a lone stream's on its one compute unit, in
+// units of the one-workgroup-per-stream kernel's cost per byte on a full chip -- for the kernel that will decode the others: plan_fill)
+static int decode_route(const unsigned int* src_sizes, int n, int cus, int mode, double dp_cost, double dp_solo, int* order, int* n_multipass) {
     if (!src_sizes || !order || !n_multipass || n < 0 || cus <= 0) return fail(SQOA_HIP_EINVAL, "sqoa_hip_decode_route: bad arguments");
     std::vector<int> ids(n);
     for (int i = 0; i < n; ++i) ids[i] = i;
@@ -271,7 +288,7 @@ int sqoa_hip_decode_route(const unsigned int* src_sizes, int n, int cus, int mod
         for (size_t k = 0; k <= (size_t)n; ++k) {
             const double bk = k < (size_t)n ? (double)src_sizes[ids[k]] : 0.0;
             const double rest = bytes - head;
-            const double cost = SQOA_DP_COST * head + (SQOA_DP_SOLO * bk > rest ? SQOA_DP_SOLO * bk : rest);
+            const double cost = dp_cost * head + (dp_solo * bk > rest ? dp_solo * bk : rest);
             if (k == 0 || cost < best) { best = cost; k_best = k; }
             if (k == (size_t)n || src_sizes[ids[k]] < SQOA_DP_MIN_BYTES) break;
             head += bk;
@@ -427,7 +444,13 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
         std::vector<int> order(ids_a.size());
         int n_multi = 0;
-        int rc = sqoa_hip_decode_route(sizes.data(), (int)sizes.size(), cus, mode, order.data(), &n_multi);
+        // (streams to four channels at aligned addresses will take the balanced kernel, which is 12 % faster on a full chip and a third
+        // faster with a compute unit to itself than the kernel the model's constants were fitted to: tools/time_few.py, 256 streams of
+        // 1 Mpixel 1.37 ms chained against 1.56 in three passes, 1024 of them 2.59 against 5.96)
+        bool bal_cand = !ids_a.empty() && bytes / ids_a.size() >= (12u << 10) && !p->small;
+        for (int i : ids_a) if (jobs[i].desc.channels != 4 || (jobs[i].dst & 3ull)) bal_cand = false;
+        if (const char* kb = getenv("SQOA_HIP_DEC_BAL")) if (kb[0] == '0') bal_cand = false;
+        int rc = decode_route(sizes.data(), (int)sizes.size(), cus, mode, bal_cand ? SQOA_DP_COST_BAL : SQOA_DP_COST, bal_cand ? SQOA_DP_SOLO_BAL : SQOA_DP_SOLO, order.data(), &n_multi);
         if (rc) return rc;
         std::vector<int> sorted(ids_a.size());
         for (size_t k = 0; k < ids_a.size(); ++k) sorted[k] = ids_a[order[k]];
@@ -507,6 +530,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             }
         }
     }
+    p->lazy_skip = p->skipped_last = p->launched = false;
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
     p->n_qoi = (int)ids_b.size();
@@ -718,8 +742,10 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
             HIP_TRY(sqoa_launch_decode_wave(p->d_jobs, p->d_ids + p->n_sqoa - p->n_chain_b, p->n_chain_b, p->shape_b, p->d_results, p->side), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipEventRecord(p->ev_join, p->side), SQOA_HIP_ELAUNCH);
         }
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, fork ? 1 : 0, fork ? (void*)p->ev_join : nullptr, p->wave_only, &p->dp,
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, fork ? 1 : 0, fork ? (void*)p->ev_join : nullptr, (p->wave_only || p->lazy_skip) ? 1 : 0, &p->dp,
                                    p->d_results, s), SQOA_HIP_ELAUNCH);
+        p->skipped_last = p->lazy_skip && !p->wave_only;
+        p->launched = true;
     }
     return 0;
 }
@@ -747,6 +773,21 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
     HIP_TRY(plan_wait(p), SQOA_HIP_ELAUNCH);
     if (n) HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
+    if (p->kind == SQOA_HIP_DECODE && !p->wave_only && p->launched && n) {
+        static const bool lazy = [] { const char* k = getenv("SQOA_HIP_DEC_LAZY"); return !(k && k[0] == '0'); }();
+        bool slow = false, used = false;
+        for (int i = 0; i < n; ++i) {
+            slow = slow || out[i].status == SQOA_HIP_ST_SLOWPATH;
+            used = used || reinterpret_cast<const unsigned char*>(&out[i].desc)[11] != 0;
+        }
+        if (p->skipped_last && slow) {
+            // the launch left the kernels behind the wave decoder out and a stream needed them after all: now, then the rows once more
+            HIP_TRY(sqoa_launch_decode_standby(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->d_results, p->stream), SQOA_HIP_ELAUNCH);
+            HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
+            HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
+            p->lazy_skip = false; p->skipped_last = false;
+        } else if (n == p->n && lazy) p->lazy_skip = !used && !slow;   // (a full view of the launch: no job took them -- the next launch does without)
+    }
     return 0;
 }
 
