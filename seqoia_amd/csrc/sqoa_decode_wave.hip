@@ -1027,8 +1027,8 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 // `shape` bit 1: TWELVE stream bytes per lane instead of eight (768-byte chunks).  What a chunk costs whatever its size -- the two
 // chain hops, the three wave scans, the scalar control around them: 134 of 480 VALU and most of the scalar instructions -- is
 // spread over 1.5 x the bytes; the walk keeps its eight record slots per lane (DEC_R).  Headline batch 3.41 -> 3.09 ms, icons
-// 4096 x 512 x 512 1.94 -> 1.77 ms, C5 rank shard 12.7 -> 12.0 ms.  The plan asks for it when every stream is decoded to FOUR
-// channels: to three (byte stores, three per pixel) the stores are what the waves queue for, and twelve bytes per lane spread a
+// 4096 x 512 x 512 1.94 -> 1.77 ms, C5 rank shard 12.7 -> 12.0 ms.  The plan asks for it when the jobs that state four output channels
+// carry at least 3/4 of the launch's stream bytes and the streams average 12 KB or more (plan_fill, sqoa_runtime.hip): to three (byte stores, three per pixel) the stores are what the waves queue for, and twelve bytes per lane spread a
 // store instruction's 64 pixels over 1.5 x the cache lines -- photo 1024 x 1 Mpixel RGB 2.90 -> 3.16 ms (11 % FEWER instructions,
 // 24 % more issue-stall cycles: profiles/r04_a_photo_rgb_*).
 // `shape` bit 3: the BALANCED kernel (sqoa_decode_bal.hip: a lane owns consecutive ops, not consecutive bytes; 1024-byte chunks) -- the

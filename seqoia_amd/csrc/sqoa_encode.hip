@@ -1350,7 +1350,11 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         PHASE(5);
         chain_post(&s_pos[w], j + 1, pos + sbase, lane);
 #ifndef SQOA_DBG_NOFLUSH
+#ifdef SQOA_DBG_ALIGNED_POS   // timing experiments only (wrong output): every flush at a 16-byte-aligned address
+        flush_stage(stage, sbase, dst + (pos & ~15u), lane);
+#else
         flush_stage(stage, sbase, dst + pos, lane);
+#endif
 #endif
         PHASE(6);
         }

@@ -25,5 +25,8 @@ u, inv = np.unique(key, return_inverse=True)
 cu_end = np.array([e0[inv == k].max() for k in range(len(u))]); cu_bytes = np.array([lens[inv == k].sum() for k in range(len(u))])
 print(f"{len(u)} compute units, workgroups per CU {np.bincount(np.bincount(inv))}; CU end time us: median {np.median(cu_end):.0f} p99 {np.percentile(cu_end, 99):.0f} max {cu_end.max():.0f}; "
       f"stream bytes per CU max / mean {cu_bytes.max() / cu_bytes.mean():.4f}; corr(CU end, CU bytes) {np.corrcoef(cu_end, cu_bytes)[0, 1]:.3f}")
-names = ["stage+parse", "parse chain", "walk", "scans", "pos/px chain wait", "store", "-", "loop glue"]
+# (decode_wave_kernel marks parse / parse chain / walk / scans / chain wait / stores; the balanced kernel parse / parse chain / starts / walk / scans + chain wait / stores)
+bal = os.environ.get("SQOA_HIP_DEC_BAL", "") != "0"
+names = (["parse", "parse chain", "starts", "walk", "scans + chain wait", "store", "-", "loop glue"] if bal else
+         ["stage+parse", "parse chain", "walk", "scans", "pos/px chain wait", "store", "-", "loop glue"])
 print("decode wave 0 time by phase (mean % over images):", ", ".join(f"{a} {v:.1f}" for a, v in zip(names, (100 * ph / ph.sum(1, keepdims=True)).mean(0))))
