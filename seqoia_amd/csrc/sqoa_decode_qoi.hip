@@ -55,6 +55,9 @@ namespace sqoa {
 #ifndef SQOA_QDEC_PRIO
 #define SQOA_QDEC_PRIO 3
 #endif
+#ifndef SQOA_QDEC_BAL   // the producers' walk balanced over the lanes (round 5)
+#define SQOA_QDEC_BAL 1
+#endif
 constexpr int QK_LB = 8;                          // stream bytes per lane
 constexpr int QK_CHUNK = 64 * QK_LB;              // stream bytes per chunk
 constexpr int QK_LDS_DW = QK_CHUNK / 4 + 8;       // staged dwords: chunk + look-ahead + misalignment
@@ -124,7 +127,7 @@ static_assert(QK_CHUNK == DP_CHUNK_BYTES, "the speculative pass indexes the pass
 // and at the end of its own chunks; dq_verify_kernel accepts the stream only if EVERY workgroup's guessed start state equals the
 // end state of the workgroup in front -- by induction from the first one, which starts exactly, all pixels are then the
 // reference's -- and leaves it to the one-workgroup decoder (status still SLOWPATH) otherwise.
-template <int W, bool SPEC = false>
+template <int W, bool SPEC = false, bool BAL = SQOA_QDEC_BAL != 0>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_qoi_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                                                    const int* __restrict__ job_ids,
                                                                                                    sqoa_hip_result* __restrict__ results,
@@ -488,13 +491,18 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         // ---- parse: the state in front of every lane's first byte (A, D1..D4; X past the chunk area) ----
         QP(1);
         const unsigned long long own = lds_read8(lds, loff);
-        Fn F{ID_LO, ID_HI};
+        // (the table reads together, waited for once: the empty asm wants all eight in registers)
+        uint32_t pflo[QK_LB];
 #pragma unroll
         for (int k = 0; k < QK_LB; ++k) {
             const uint32_t b = (uint32_t)(own >> (8 * k)) & 0xffu;
-            const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
-            F = compose(Fn{flo, 0x07060403u}, F);
+            pflo[k] = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
         }
+        if constexpr (BAL)
+        asm volatile("" : "+v"(pflo[0]), "+v"(pflo[1]), "+v"(pflo[2]), "+v"(pflo[3]), "+v"(pflo[4]), "+v"(pflo[5]), "+v"(pflo[6]), "+v"(pflo[7]));
+        Fn F{ID_LO, ID_HI};
+#pragma unroll
+        for (int k = 0; k < QK_LB; ++k) F = compose(Fn{pflo[k], 0x07060403u}, F);
         const Fn Fi = wave_compose_scan(F);
         const Fn G{bcast_lane(Fi.lo, 63), bcast_lane(Fi.hi, 63)};
         const Fn Fx{shift_up1(Fi.lo, ID_LO), shift_up1(Fi.hi, ID_HI)};
@@ -509,20 +517,117 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         if (!g_const && !last_chunk) qk_post(my_parse, c + 1, apply(G, st_in), lane);
         const uint32_t lst = apply_perm(Fx, st_in);
 
+        uint32_t rv[QK_LB], rm[QK_LB];   // record value; record word: 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixels << 9
+        uint32_t iters = 0, obase = 0, ctot = 0, T = 0, closed = 0;
+        Xf Tl{0u, 0u};                   // my ops so far, since my last INDEX op (or my first op)
+        typedef const __attribute__((address_space(3))) uint32_t* lcptr32;
+        typedef const __attribute__((address_space(3))) u32x4* lcptr128;
+        const uint32_t qtab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u32x4*)s_qtab;
+        if constexpr (BAL) {
+        // ---- the chunk's ops dealt out evenly over the lanes (round 5: the balanced walk of sqoa_decode_bal.hip) ----
+        // A lane that walks the ops that start in ITS 8 bytes runs as many iterations as the busiest lane has ops -- eight wherever a chunk holds
+        // a stretch of one-byte ops (DIFF, INDEX, RUN: every gradient), for the four or so ops a lane has on average.  Here: (1) the parser
+        // state in front of every byte of mine (the functions applied once more, one v_perm_b32 a byte), "an op starts here" = that state is
+        // A on a live byte, the flags gathered into a mask, their ranks by the wave scan that counted the ops anyway; (2) the starts' byte
+        // offsets to a list by rank -- in my record buffer, which is free: the pixels of my previous chunk go out FIRST now (the resolver is
+        // six chunks of the other producers away from needing this one's records); (3) q = ceil(T / 64) ops per lane, q - 1 for the lanes
+        // from k = T - 64 (q - 1) on, whose slot 0 stays empty: lane j's slot i holds op j (q - 1) + min(j, k) + i - (slot 0 empty), and that
+        // rank IS the record's place in stream order.
+        QP(2);
+        uint32_t M;   // bit k: an op starts at my byte k
+        {
+            uint32_t st = lst, o[QK_LB - 1];
+#pragma unroll
+            for (int k = 0; k < QK_LB - 1; ++k) {
+                const uint32_t b = (uint32_t)(own >> (8 * k)) & 0xffu;
+                const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
+                st = __builtin_amdgcn_perm(0x07060403u, flo, st);   // (byte 0: the state behind byte k)
+                o[k] = st;
+            }
+            const uint32_t p01 = __builtin_amdgcn_perm(o[0], lst, 0x0c0c0400u), p23 = __builtin_amdgcn_perm(o[2], o[1], 0x0c0c0400u);
+            const uint32_t p45 = __builtin_amdgcn_perm(o[4], o[3], 0x0c0c0400u), p67 = __builtin_amdgcn_perm(o[6], o[5], 0x0c0c0400u);
+            const uint32_t w0 = __builtin_amdgcn_perm(p23, p01, 0x05040100u), w1 = __builtin_amdgcn_perm(p67, p45, 0x05040100u);   // the states in front of my bytes 0..3, 4..7
+            const uint32_t f0 = ~(w0 + 0x07070707u) & 0x08080808u, f1 = ~(w1 + 0x07070707u) & 0x08080808u;                          // 0x08 where the state is A (0)
+            M = (__builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false) >> 3) & ((1u << nlive) - 1u);
+        }
+        const uint32_t nops = (uint32_t)__builtin_popcount(M);
+        const uint32_t oinc = wave_incl_scan(nops);
+        T = bcast_lane(oinc, 63);
+
+        // ---- my buffer still holds my previous chunk: its pixels go out now ----
+        QP(3);
+        if (!flush_held()) break;
+        uint32_t* list = reinterpret_cast<uint32_t*>(rec) + 8;   // (one entry in front for the lanes whose slot 0 is empty, room behind for the last lanes' reads)
+        {
+            uint32_t m = M, t;
+            const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)list + 4u * (oinc - nops);
+            const uint32_t data0 = (uint32_t)(QK_LB * lane);
+            const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+#define SQOA_QLIST_STEP(OFF)                        \
+            "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"      \
+            "v_ffbl_b32_e32 %[t], %[m]\n\t"           \
+            "v_add_u32_e32 %[t], %[t], %[d0]\n\t"     \
+            "ds_write_b32 %[a], %[t] offset:" #OFF "\n\t" \
+            "v_add_u32_e32 %[t], -1, %[m]\n\t"        \
+            "v_and_b32_e32 %[m], %[t], %[m]\n\t"
+            asm volatile(
+                SQOA_QLIST_STEP(0) SQOA_QLIST_STEP(4) SQOA_QLIST_STEP(8) SQOA_QLIST_STEP(12)
+                SQOA_QLIST_STEP(16) SQOA_QLIST_STEP(20) SQOA_QLIST_STEP(24) SQOA_QLIST_STEP(28)
+                "s_mov_b64 exec, %[ex]\n\t"
+                "s_nop 4"
+                : [m] "+v"(m), [t] "=&v"(t) : [a] "v"(laddr), [d0] "v"(data0), [ex] "s"(exec_in) : "memory", "vcc");
+#undef SQOA_QLIST_STEP
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t q = bcast_first((T + 63u) >> 6);
+        const uint32_t kq = bcast_first(T - 64u * (q - 1u));
+        const bool first_slot = (uint32_t)lane < kq;
+        const uint32_t r_slot0 = q ? (uint32_t)lane * (q - 1u) + ((uint32_t)lane < kq ? (uint32_t)lane : kq) - (first_slot ? 0u : 1u) : 0u;
+        // (rv[]: until the op is decoded, its start)
+#pragma unroll
+        for (int i = 0; i < QK_LB; ++i) rv[i] = list[r_slot0 + i];
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cl = 0;
+        uint32_t seen = 0;               // (closed) bit i: an INDEX op of mine sits at or in front of my slot i (its record is final as it is)
+        const uint32_t cb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + (gs & 3u);
+        iters = q;
+#pragma unroll
+        for (int i = 0; i < QK_LB; ++i) {
+            if ((uint32_t)i >= q) break;
+            rm[i] = 0u;
+            if (i != 0 || first_slot) {
+                const uint32_t a = cb_addr + rv[i];
+                lcptr32 pw = (lcptr32)(uintptr_t)(a & ~3u);
+                const uint32_t d0 = pw[0], d1 = pw[1], d2 = pw[2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                const u32x4 e = *(lcptr128)(uintptr_t)(qtab_addr + (lo & 0xffu) * 16u);
+                const uint32_t nib = (((lo >> 12) & 0xfu) | ((lo << 8) & 0xf0000u)) & e.w;     // LUMA: dr_dg, db_dg (seqoia.h:765-768)
+                const uint32_t rel = ((e.z + nib) & 0x00ff00ffu) | (e.w & 0xff00u);
+                const uint32_t base = __builtin_amdgcn_alignbit(hi, lo, 8);                     // RGB / RGBA: the bytes behind the op byte
+                const uint32_t v = (rel & ~e.y) | (base & e.y);
+                const uint32_t xm = sra31(e.x << 15);                                           // ~0: an INDEX op (bit 16 of the table word)
+                Tl.v = add8(Tl.v & ~e.y, v) & ~xm;
+                Tl.abs = (Tl.abs | e.y) & ~xm;
+                seen |= xm;
+                closed |= seen & (1u << i);
+                rv[i] = Tl.v;
+                rm[i] = (e.x >> 16) | ((Tl.abs >> 22) & 6u);
+                cl += e.x >> 25;
+            }
+        }
+        obase = r_slot0;
+        ctot = bcast_lane(wave_incl_scan(cl), 63);   // pixels this chunk's ops produce
+        } else {
         // ---- walk: my ops, in order (seqoia.h:740-775 with qoi_compat) ----
         QP(2);
         uint32_t pos = first_op_offset<QK_LB>(lst);
         // Between two INDEX ops pixel values do not depend on the index: every op's record is its pixel RELATIVE to the INDEX op
         // (or the chunk start) its segment begins at.  Inside the lane the ops' transforms are composed as they are decoded; what
         // the lanes below contribute comes from one segmented scan over the lanes' totals further down.
-        uint32_t rv[QK_LB], rm[QK_LB];   // record value; record word: 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixels << 9
-        uint32_t nops = 0, iters = QK_LB, cl = 0;
-        Xf Tl{0u, 0u};                   // my ops so far, since my last INDEX op (or my first byte)
-        uint32_t closed = 0, seen = 0;   // bit i: an INDEX op of mine sits at or in front of my op i (its record is final as it is)
+        uint32_t nops = 0, cl = 0;
+        iters = QK_LB;
+        uint32_t seen = 0;               // (closed) bit i: an INDEX op of mine sits at or in front of my op i (its record is final as it is)
         const uint32_t lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds + loff;
-        const uint32_t qtab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) u32x4*)s_qtab;
-        typedef const __attribute__((address_space(3))) uint32_t* lcptr32;
-        typedef const __attribute__((address_space(3))) u32x4* lcptr128;
 #pragma unroll
         for (int i = 0; i < QK_LB; ++i) {
             if (__ballot(pos < nlive) == 0ull) { iters = i; break; }
@@ -565,13 +670,14 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
         iters = bcast_first(iters);  // wave-uniform by construction: scalar slot tests below
         const uint32_t oinc = wave_incl_scan(nops);
-        const uint32_t T = bcast_lane(oinc, 63);
-        const uint32_t obase = oinc - nops;
-        const uint32_t ctot = bcast_lane(wave_incl_scan(cl), 63);   // pixels this chunk's ops produce
+        T = bcast_lane(oinc, 63);
+        obase = oinc - nops;
+        ctot = bcast_lane(wave_incl_scan(cl), 63);   // pixels this chunk's ops produce
 
         // ---- my buffer still holds my previous chunk: its pixels go out now (the resolver has long been through it) ----
         QP(3);
         if (!flush_held()) break;
+        }
 
         // ---- what enters my lane: the lanes below me back to the nearest one that holds an INDEX op (its ops behind that op) ----
         QP(4);
@@ -770,6 +876,8 @@ extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sq
 extern "C" size_t sqoa_dq_state_bytes(void) { return 2 * sizeof(sqoa::dq_state); }   // per workgroup row of the tables
 
 // `small`: the plan's streams are short (many more images than the chip holds workgroups of the large shape)
+// (The producers' walk balanced over the lanes for every plan: on RUN-heavy streams, whose chunks hold few ops, it is as fast as the walk
+// over a lane's own bytes -- 4096 icons of 512 x 512: 2.17 against 2.18 ms, same call -- and on the headline batch 8.18 -> 7.75 ms.)
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     if (small) hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W_SMALL>), dim3(n), dim3(SQOA_QDEC_W_SMALL * 64), 0, stream, d_jobs, d_ids, d_results);
