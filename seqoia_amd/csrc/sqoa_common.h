@@ -159,6 +159,31 @@ SQOA_DEV uint32_t chain_poll(const unsigned long long* slot, uint32_t tag, uint3
     return t;
 }
 
+// One 8-byte chain word -- tag in the high half, value in the low half -- written to LDS by lane 0 alone.  Hand-written: `if (lane == 0) store`
+// makes the compiler keep "lane == 0" as a 64-bit lane mask across the kernel's main loop -- an SGPR pair the encoder has not got: spilled, and
+// fetched back with two v_readlane_b32 (slow-class VALU) in front of every post, three or four times a sub-tile -- and wrap the store in a
+// saveexec / branch / restore.  Here EXEC is lane 0 for the one ds_write_b64.  (LDS executes a wave's instructions in order: what the wave wrote to
+// LDS before is there when the word is -- the "release" the chains need; nothing that crosses waves in these kernels goes through global memory.)
+#ifndef SQOA_ASM_POST
+#define SQOA_ASM_POST 1
+#endif
+SQOA_DEV void lds_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
+#if SQOA_ASM_POST
+    (void)lane;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)slot;
+    const unsigned long long w = (unsigned long long)tag << 32 | val;
+    unsigned long long ex;
+    asm volatile(
+        "s_mov_b64 %[ex], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b64 %[a], %[w]\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [ex] "=&s"(ex) : [a] "v"(addr), [w] "v"(w) : "memory");
+#else
+    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
 SQOA_DEV uint32_t bcast_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 SQOA_DEV uint32_t bcast_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 

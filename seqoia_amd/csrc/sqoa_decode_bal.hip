@@ -60,9 +60,7 @@ SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t
     const uint32_t t = chain_poll<SLEEP>(slot, tag, DEC_ABORT_TAG, val);
     return t == tag ? 0u : t == DEC_ABORT_TAG ? 1u : 2u;
 }
-SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
-    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) { lds_post(slot, tag, val, lane); }
 template <int I, int N, class F>
 SQOA_DEV void static_for(F&& f) {
     if constexpr (I < N) {
@@ -525,9 +523,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             BPHASE(4);
             exit_v = xf_apply(Tg, px_in);   // (wave-uniform: scalar arithmetic)
             pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-            if (!last_chunk && lane == 0) {
-                __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!last_chunk) {   // (the position word first: a waiter that sees the pixel word's tag finds it there)
+                lds_post(&s_pos[w], c + 1, pos_out, lane);
+                lds_post(&s_px[w], c + 1, exit_v, lane);
             }
             if (pos_in < N) {
                 // ---- the chunk's pixels: to LDS in position order, out as 16-byte pieces --------------------------------------------------

@@ -101,9 +101,7 @@ SQOA_DEV bool qk_wait(unsigned long long* slot, uint32_t tag, uint32_t& val, uin
 #endif
 }
 // (release: everything the wave wrote to LDS before -- index updates included -- is done when the tag becomes visible)
-SQOA_DEV void qk_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
-    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+SQOA_DEV void qk_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) { lds_post(slot, tag, val, lane); }
 
 // v_cndmask_b32 with the lane mask in an SGPR pair: the serial section keeps its lane sets as wave-uniform 64-bit masks
 SQOA_DEV uint32_t select_mask(uint32_t if_clear, uint32_t if_set, unsigned long long mask) {

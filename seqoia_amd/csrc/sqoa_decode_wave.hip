@@ -64,9 +64,7 @@ SQOA_DEV uint32_t chain_wait_rc(unsigned long long* slot, uint32_t tag, uint32_t
 #endif
 }
 
-SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
-    if (lane == 0) __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+SQOA_DEV void post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) { lds_post(slot, tag, val, lane); }
 
 // for (i = I; i < N; ++i) if (!f(i)) break; with i a compile-time constant: the per-op register arrays of the walk are indexed by it,
 // and a loop the compiler declines to unroll fully (it did at 12 ops per lane) sends them to scratch memory
@@ -779,9 +777,9 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         DPHASE(4);
         const uint32_t exit_v = xf_apply(Tg, px_in);
         const uint32_t pos_out = pos_in + ctot > N ? N : pos_in + ctot;
-        if (!last_chunk && lane == 0) {
-            __hip_atomic_store(&s_pos[w], (unsigned long long)(c + 1) << 32 | pos_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&s_px[w], (unsigned long long)(c + 1) << 32 | exit_v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!last_chunk) {   // (the position word first: a waiter that sees the pixel word's tag finds it there)
+            lds_post(&s_pos[w], c + 1, pos_out, lane);
+            lds_post(&s_px[w], c + 1, exit_v, lane);
         }
 
         if (pos_in < N) {

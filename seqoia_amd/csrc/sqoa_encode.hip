@@ -74,10 +74,7 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
     }
 }
 
-SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) {
-    if (lane == 0)
-        __hip_atomic_store(slot, (unsigned long long)tag << 32 | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) { lds_post(slot, tag, val, lane); }
 
 // Op bytes of a pixel that differs from its predecessor (reference seqoia.h:584-635),
 // little-endian in lo (bytes 0-3) / hi (byte 4).  QOI index hits are patched in by the caller.
