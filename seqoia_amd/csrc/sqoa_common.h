@@ -159,6 +159,15 @@ SQOA_DEV uint32_t chain_poll(const unsigned long long* slot, uint32_t tag, uint3
     return t;
 }
 
+// EXEC as a value, for the hand-written blocks that narrow it (v_cmpx) and put it back.  Read by an instruction of its own: handed the builtin's
+// value, the compiler may give such a block the EXEC register itself as its "saved" operand -- `s_mov_b64 exec, exec`, the narrowed mask stays,
+// and a wave whose mask came out empty never finishes (seen once, round 5).
+SQOA_DEV unsigned long long exec_saved() {
+    unsigned long long e;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(e));
+    return e;
+}
+
 // One 8-byte chain word -- tag in the high half, value in the low half -- written to LDS by lane 0 alone.  Hand-written: `if (lane == 0) store`
 // makes the compiler keep "lane == 0" as a 64-bit lane mask across the kernel's main loop -- an SGPR pair the encoder has not got: spilled, and
 // fetched back with two v_readlane_b32 (slow-class VALU) in front of every post, three or four times a sub-tile -- and wrap the store in a

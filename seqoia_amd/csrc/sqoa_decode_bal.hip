@@ -376,7 +376,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             uint32_t m = M, t;
             const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) list_t*)list + (uint32_t)sizeof(list_t) * rank0;
             const uint32_t data0 = (uint32_t)(LB * lane);
-            const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+            const unsigned long long exec_in = exec_saved();
 #if SQOA_BAL_LIST32
 #define SQOA_BAL_LIST_WR "ds_write_b32"
 #else
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         }
                     }
                 };
-                const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+                const unsigned long long exec_in = exec_saved();
                 if (ctot <= (uint32_t)PIX_CAP) {   // the common chunk: one window, every position inside it
                     const uint32_t my_addr = scr_addr + (my_rel << 2);
                     static_for<0, R>([&](auto i_tag) -> bool {

@@ -50,10 +50,16 @@ namespace sqoa {
 #define SQOA_QDEC_SLEEP 16      // producers: x 64 cycles between two looks at a chain word
 #endif
 #ifndef SQOA_QDEC_RSLEEP
-#define SQOA_QDEC_RSLEEP 1      // the resolver, when the next chunk's records are not there yet
+#define SQOA_QDEC_RSLEEP 8      // the resolver, when the next chunk's records are not there yet (1 -> 8 in round 5: icons 1 % faster, the rest equal)
 #endif
 #ifndef SQOA_QDEC_PRIO
 #define SQOA_QDEC_PRIO 3
+#endif
+#ifndef SQOA_QDEC_LDS_STORES   // the producers' pixels through LDS in position order, out as 16-byte pieces (round 5; with SQOA_QDEC_BAL)
+#define SQOA_QDEC_LDS_STORES 1
+#endif
+#ifndef SQOA_QDEC_SEQ_MAX   // the resolver: groups of up to this many INDEX ops are settled one op after the other, in registers (round 5); 0: always the fixed point
+#define SQOA_QDEC_SEQ_MAX 4
 #endif
 #ifndef SQOA_QDEC_BAL   // the producers' walk balanced over the lanes (round 5)
 #define SQOA_QDEC_BAL 1
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // per op of the producer's chunk, in stream order: transform value bytes (later: the transform scanned over its segment,
     // later still: the op's pixel), and 1 = INDEX | absolute channels (2 = rgb, 6 = rgba) | slot << 3 | pixel count << 9
     // (one 8-byte record: the resolver -- the image's serial path -- takes a group's 64 records with one LDS instruction)
-    __shared__ uint2 s_rec[P][QK_CHUNK];
+    __shared__ __attribute__((aligned(16))) uint2 s_rec[P][QK_CHUNK];
     __shared__ unsigned long long s_tab[64];       // the colour index (seqoia.h:712, :785-787): stamp << 32 | value
     __shared__ unsigned long long s_parse[2][P];
     __shared__ unsigned long long s_pos[P];
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ unsigned long long s_done[P];       // resolver -> producer: chunk + 1 << 32 | the pixel the chunk ends with
     __shared__ unsigned long long s_smask[64];     // resolver scratch: per index slot, the lanes of the group whose pixel hashes to it
     __shared__ uint32_t s_go;
+    [[maybe_unused]] __shared__ uint32_t s_hwid;   // (diagnostic builds)
 
     SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
@@ -245,6 +252,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // ================= the resolver: every chunk's serial section, in stream order ==========================================
     if (w == 0) {
         __builtin_amdgcn_s_setprio(SQOA_QDEC_PRIO);   // the image's critical path: ahead of the waves that are preparing later chunks
+#ifdef SQOA_QDEC_HWDUMP
+        { uint32_t h, x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+          if (lane == 0) s_hwid = (h & 0x0fffffffu) | x << 28; }
+#endif
         const unsigned long long bit = 1ull << lane, lt_mask = bit - 1ull;
         // seqoia.h:716-719; SPEC, a warm-up that does not begin at the stream's start: pass 2's guess of the pixel there (decode_wave_kernel)
         uint32_t pxv = SPEC && c_begin ? bcast_first(rows[c_begin / dp_per].px_in) : kPxInit;
@@ -314,6 +325,48 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         RPH(4);
                         commit(val, qoi_hash(val));
                         continue;
+                    }
+                    if constexpr (SQOA_QDEC_SEQ_MAX > 0) {
+                        // A group with FEW INDEX ops (two or three on photo-like content): one after the other, in stream order, and without a
+                        // round trip to LDS between them.  When INDEX op l's turn comes every lane below it holds its final pixel; "the most
+                        // recent earlier op of the group whose pixel hashes to my slot" is then one compare of all lanes' hashes with the
+                        // slot (a scalar), a mask of the lanes below l, a count of leading zeros -- scalar instructions -- and a v_readlane;
+                        // failing that the index entry, fetched for all the group's INDEX ops at once in front of the loop.  The lanes from l
+                        // on take the pixel as their segment's start (the next INDEX op overrides it from its own lane on) and every lane
+                        // recomputes pixel and hash: seven VALU instructions.  About a hundred cycles per INDEX op, where the fixed point
+                        // below is four dependent LDS round trips plus its 64-bit mask arithmetic per round whatever the count.
+                        #ifdef SQOA_QDEC_SEQ_RT   // (A/B builds: the path compiled in and never taken -- dp_span is 1 in the launches of this instance)
+                        if ((uint32_t)__builtin_popcountll(idxmask) <= dp_span - 1u) {
+#else
+                        if ((uint32_t)__builtin_popcountll(idxmask) <= (uint32_t)SQOA_QDEC_SEQ_MAX) {
+#endif
+                            tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                            const uint32_t tabv = (uint32_t)tab64;
+                            uint32_t hx = hopen, Xl = 0;
+                            unsigned long long rem = idxmask;
+                            RPH(3);
+                            for (;;) {
+                                val = add8(hx & nabs, Sv);
+                                hv = qoi_hash(val);
+                                if (rem == 0ull) break;
+                                const int l = __builtin_ctzll(rem);
+                                rem &= rem - 1ull;
+                                const uint32_t sl = bcast_lane(slot, l);
+                                const unsigned long long earlier = __ballot(hv == sl) & ((1ull << l) - 1ull);
+                                Xl = earlier ? bcast_lane(val, 63 - __builtin_clzll(earlier)) : bcast_lane(tabv, l);
+                                if constexpr (SPEC) {
+                                    if (c >= chunk_first && earlier == 0ull && bcast_lane((uint32_t)(tab64 >> 32), l) <= (chunk_first << 10)) rmask |= 1ull << sl;
+                                }
+                                hx = (uint32_t)lane >= (uint32_t)l ? Xl : hx;
+                            }
+                            RPH(4);
+                            hopen = Xl;
+#ifdef SQOA_QTRACE
+                            ph[9] += 1;
+#endif
+                            commit(val, hv);
+                            continue;
+                        }
                     }
                     {
                         // the INDEX op at or below me that my segment starts at (none: it starts from the pixel entering the group)
@@ -416,7 +469,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
     // The pixels of the chunk whose records sit in my buffer, once the resolver is done with them: literal ops lane-local,
     // runs by the whole wave; the last chunk repeats the final pixel to the end of the image (seqoia.h:726).
-    uint32_t held = ~0u, held_T = 0, held_pos = 0, held_out = 0;   // the chunk in my buffer, its ops, its first pixel, the pixel behind it
+    uint32_t held = ~0u, held_T = 0, held_pos = 0, held_out = 0, held_ctot = 0;   // the chunk in my buffer, its ops, its first pixel, the pixel behind it
     auto flush_held = [&]() -> bool {
         if (held == ~0u) return true;
         uint32_t pxv = 0;
@@ -425,6 +478,81 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #ifdef SQOA_DBG_Q_NOOUT
         P0 = N;
 #endif
+        if constexpr (BAL && SQOA_QDEC_LDS_STORES != 0) {
+            // The common chunk (dword pixels, all of them inside the image, no more than the buffer holds): as decode_bal_kernel stores --
+            // my own q records back into registers (the lane that made them takes them: their ranks, hence their pixel positions, follow
+            // from T alone), ONE scan of the lanes' pixel counts where the loop below runs one per 64 records, every op's pixel into the
+            // record buffer -- free once the records are in registers -- at its position in the chunk, RUNs filled in by the wave, and out
+            // as 16-byte pieces: 4 KB a store instruction instead of 64 scattered dwords.
+            constexpr uint32_t CAP = 2u * (uint32_t)QK_CHUNK - 8u, DUMP = 4u * (CAP + 4u);
+            if (dw_out && held_T != 0u && held_ctot <= CAP && P0 + held_ctot <= N) {
+                const uint32_t hq = bcast_first((held_T + 63u) >> 6), hk = bcast_first(held_T - 64u * (hq - 1u));
+                const bool hfirst = (uint32_t)lane < hk;
+                const uint32_t h0 = (uint32_t)lane * (hq - 1u) + ((uint32_t)lane < hk ? (uint32_t)lane : hk) - (hfirst ? 0u : 1u);
+                uint32_t hv[QK_LB], hc[QK_LB], lc = 0, longest = 0;
+#pragma unroll
+                for (int i = 0; i < QK_LB; ++i) {
+                    if ((uint32_t)i >= hq) break;
+                    const uint2 r = rec[h0 + i];
+                    hv[i] = r.x;
+                    hc[i] = i == 0 && !hfirst ? 0u : r.y >> 9;
+                    lc += hc[i];
+                    longest = hc[i] > longest ? hc[i] : longest;
+                }
+                const uint32_t pinc = wave_incl_scan(lc);
+                const uint32_t pix_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)rec;
+                uint32_t* pix = reinterpret_cast<uint32_t*>(rec);
+                const unsigned long long exec_in = exec_saved();
+                uint32_t a = pix_addr + ((pinc - lc) << 2);
+                asm volatile("" ::: "memory");   // (every record is in a register -- or on its way, the LDS queue keeps a wave's order -- before a pixel takes its place)
+#pragma unroll
+                for (int i = 0; i < QK_LB; ++i) {
+                    if ((uint32_t)i >= hq) break;
+                    const uint32_t aa = i == 0 && !hfirst ? pix_addr + DUMP : a;   // (no op in my slot 0: to the dump words)
+                    asm volatile(
+                        "ds_write_b32 %[a], %[v]\n\t"
+                        "v_cmpx_lt_u32_e32 vcc, 1, %[c]\n\t"             // a RUN of two or more
+                        "ds_write_b32 %[a], %[v] offset:4\n\t"
+                        "s_mov_b64 exec, %[ex]\n\t"
+                        "s_nop 4"
+                        :: [c] "v"(hc[i]), [a] "v"(aa), [v] "v"(hv[i]), [ex] "s"(exec_in) : "memory", "vcc");
+                    a += hc[i] << 2;
+                }
+                if (__ballot(longest > 2u) != 0ull) {   // seqoia.h:773-775: what a RUN covers behind its first two pixels, by the whole wave
+                    uint32_t rel = pinc - lc;
+#pragma unroll
+                    for (int i = 0; i < QK_LB; ++i) {
+                        if ((uint32_t)i >= hq) break;
+                        unsigned long long runs = __ballot(hc[i] > 2u);
+                        while (runs) {
+                            const int l = __builtin_ctzll(runs);
+                            runs &= runs - 1ull;
+                            const uint32_t rp = bcast_lane(rel, l) + 2u, rc = bcast_lane(hc[i], l) - 2u, rvv = bcast_lane(hv[i], l);
+                            for (uint32_t t = (uint32_t)lane; t < rc; t += 64u) pix[rp + t] = rvv;
+                        }
+                        rel += hc[i];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    typedef u32x4 u32x4_una __attribute__((aligned(4)));
+                    typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
+                    const uint32_t n = held_ctot;
+                    for (uint32_t x0 = 0; x0 < n; x0 += 256u) {
+                        const uint32_t x = x0 + 4u * (uint32_t)lane;
+                        gptr32 o = (gptr32)out + P0 + x;
+                        if (x + 4u <= n) *(gptr128u)o = *reinterpret_cast<const u32x4*>(pix + x);
+                        else if (x < n) {                                              // the last one to three pixels
+                            o[0] = pix[x];
+                            if (x + 1u < n) o[1] = pix[x + 1];
+                            if (x + 2u < n) o[2] = pix[x + 2];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                P0 = N;   // (nothing left for the loop below)
+            }
+        }
         for (uint32_t gb = 0; gb < held_T && P0 < N; gb += 64) {
             const bool live = gb + (uint32_t)lane < held_T;
             const uint2 r = live ? rec[gb + lane] : uint2{0u, 0u};
@@ -436,7 +564,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (dw_out && P0 + gtot <= N) {
                 // the common group -- dword pixels, nothing clipped: the two predicates narrow EXEC directly (v_cmpx), the stores take
                 // the image base from an SGPR pair and a 32-bit byte offset, EXEC is put back once
-                const unsigned long long obase = job.dst, exec_in = __builtin_amdgcn_read_exec();
+                const unsigned long long obase = job.dst, exec_in = exec_saved();
                 const uint32_t off = Pp << 2, c1 = cnt - 1u;
                 asm volatile(
                     "v_cmpx_gt_u32_e32 vcc, 2, %[c1]\n\t"           // cnt is 1 or 2
@@ -465,7 +593,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         if (held == nchunks - 1) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             for (uint32_t k = held_out + lane; k < N; k += 64) put(k, pxv);
+#ifdef SQOA_QDEC_HWDUMP   // diagnostic builds: HW_ID of the resolver wave instead of the length (tools/qoi_resolver_simds.py)
+            if (!SPEC && lane == 0) res->len = (int)s_hwid;
+#else
             if (!SPEC && lane == 0) res->len = (int)(N * (uint32_t)oc);
+#endif
         }
         held = ~0u;
         return true;
@@ -560,7 +692,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             uint32_t m = M, t;
             const uint32_t laddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)list + 4u * (oinc - nops);
             const uint32_t data0 = (uint32_t)(QK_LB * lane);
-            const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+            const unsigned long long exec_in = exec_saved();
 #define SQOA_QLIST_STEP(OFF)                        \
             "v_cmpx_ne_u32_e32 vcc, 0, %[m]\n\t"      \
             "v_ffbl_b32_e32 %[t], %[m]\n\t"           \
@@ -715,7 +847,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         // ---- over to the resolver (release: the records are in LDS when the tag is) ----
         QP(7);
         qk_post(&s_ready[p], c + 1, T | (pos_in < N ? 0u : 1u << 31), lane);
-        held = c; held_T = T; held_pos = SPEC && c < chunk_first ? N : pos_in; held_out = pos_out;
+        held = c; held_T = T; held_pos = SPEC && c < chunk_first ? N : pos_in; held_out = pos_out; held_ctot = ctot;
     }
     if (!bad) flush_held();
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);

@@ -811,7 +811,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
                 // does not rely on it).
                 const uint32_t lane_off = lane_p << 2;
                 const unsigned long long obase = job.dst;
-                const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+                const unsigned long long exec_in = exec_saved();
                 static_for<0, DEC_R>([&](auto i_tag) -> bool {
                     constexpr int i = decltype(i_tag)::value;
                     if ((uint32_t)i >= iters) return false;

@@ -151,3 +151,29 @@ def test_encode_route_cuts_the_images_that_would_outlast_the_batch():
     assert k == 2 and order[:2] == [5000, 5001] and strips[0] > strips[1] >= 2 and sorted(order) == list(range(len(sizes)))
     assert route(sizes, mode=-1)[2] == 0 and route(sizes, mode=1)[2] == len(sizes)
     assert lib.sqoa_hip_encode_route(None, 1, 256, 0, None, None, None) != 0
+
+
+def test_no_kernel_restores_exec_from_exec(tmp_path):
+    """The hand-written blocks that narrow EXEC (`v_cmpx`) put it back from a copy taken by `exec_saved()` (sqoa_common.h).  Taken through the
+    compiler's builtin the copy can come out as the EXEC register itself -- `s_mov_b64 exec, exec`: the narrowed mask stays and a wave whose
+    mask is empty never ends (a hang on the GPU box in round 5, found in the disassembly).  Every gfx950 code object of the built library is
+    disassembled here and searched for that instruction."""
+    import glob
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+
+        pytest.skip("no llvm-objdump in this image")
+    lib = shutil.copy(seqoia_amd._lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert len(objs) >= 5, objs
+    kernels = 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        kernels += len(re.findall(r"^[0-9a-f]+ <_Z\w*kernel\w*>:", text, flags=re.M))
+        bad = [l for l in text.splitlines() if re.search(r"s_mov_b64\s+exec,\s*exec\b", l)]
+        assert not bad, (o, bad[:3])
+    assert kernels >= 10, kernels

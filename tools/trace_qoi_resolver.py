@@ -6,10 +6,11 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, seqoia_amd as sq, numpy as np
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-px = torch.empty((n, 1024, 1024, 4), dtype=torch.uint8, device="cuda"); sq.synth(px, "mixed", 1, 0)
+cls = sys.argv[2] if len(sys.argv) > 2 else "mixed"
+px = torch.empty((n, 1024, 1024, 4), dtype=torch.uint8, device="cuda"); sq.synth(px, cls, 1, 0)
 enc = sq.EncodePlan(px, qoi_compat=1); enc.launch(); res = enc.results()
 dec = sq.DecodePlan(enc.out, res["len"], 1024, 1024, 4); dec.launch(); dec.results()
-print(os.environ.get("SQOA_LIB", "default"), "ms", round(dec.time(3) / 3, 3))
+print(os.environ.get("SQOA_LIB", "default"), cls, "ms", round(dec.time(3) / 3, 3))
 torch.cuda.synchronize()
 tr = dec.out.view(n, -1)[:, :96].cpu().numpy().view(np.uint64).astype(np.float64)
 ok = (tr[:, 10] > 1000) & (tr[:, 10] < 20000) & (tr[:, 8] > 0)
