@@ -333,15 +333,18 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         // slot (a scalar), a mask of the lanes below l, a count of leading zeros -- scalar instructions -- and a v_readlane;
                         // failing that the index entry, fetched for all the group's INDEX ops at once in front of the loop.  The lanes from l
                         // on take the pixel as their segment's start (the next INDEX op overrides it from its own lane on) and every lane
-                        // recomputes pixel and hash: seven VALU instructions.  About a hundred cycles per INDEX op, where the fixed point
-                        // below is four dependent LDS round trips plus its 64-bit mask arithmetic per round whatever the count.
-                        #ifdef SQOA_QDEC_SEQ_RT   // (A/B builds: the path compiled in and never taken -- dp_span is 1 in the launches of this instance)
-                        if ((uint32_t)__builtin_popcountll(idxmask) <= dp_span - 1u) {
-#else
+                        // recomputes pixel and hash: seven VALU instructions.  Twenty-six instructions per INDEX op, where the fixed point
+                        // below is four dependent LDS round trips plus its 64-bit mask arithmetic per round whatever the count: headline
+                        // batch 7.67 -> 7.24 ms at a threshold of 3 to 6 ops (8: 7.31, 16: 7.97).
                         if ((uint32_t)__builtin_popcountll(idxmask) <= (uint32_t)SQOA_QDEC_SEQ_MAX) {
-#endif
-                            tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-                            const uint32_t tabv = (uint32_t)tab64;
+                            // (the entries' values alone, one register, unless the check of the speculative route wants the stamps: the half
+                            // of a 64-bit load nobody reads is the next temporary, and the wave would wait for the load before the first add)
+                            uint32_t tabv;
+                            if constexpr (SPEC) {
+                                tab64 = isx ? __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                                tabv = (uint32_t)tab64;
+                            } else
+                                tabv = isx ? __hip_atomic_load(reinterpret_cast<uint32_t*>(&s_tab[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
                             uint32_t hx = hopen, Xl = 0;
                             unsigned long long rem = idxmask;
                             RPH(3);

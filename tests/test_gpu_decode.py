@@ -746,6 +746,49 @@ def _qoi_hash(r, g, b, a=255):
     return (r * 3 + g * 5 + b * 7 + a * 11) % 64   # seqoia.h:785-787 (qoi_compat)
 
 
+def test_qoi_groups_of_few_index_ops_match_oracle(sq, orc, route):
+    """The resolver settles a 64-op group that holds up to SQOA_QDEC_SEQ_MAX (4) INDEX ops one op after the other in registers, and a group with
+    more by the fixed point: bodies whose INDEX ops are SPARSE, at densities from one in 64 ops to ten in 64 -- groups on both
+    sides of the threshold, next to each other in one stream -- between DIFF / LUMA ops (every pixel lands in some slot: most INDEX ops find
+    their slot written earlier in their own group, by a relative op or by another INDEX op), literals and short runs.  Byte for byte the
+    reference's pixels, one workgroup per stream and on the speculative route."""
+    import torch
+
+    o = orc.best()
+    rng = np.random.default_rng(4242)
+    w = h = 192
+    streams = []
+    for k, per64 in enumerate((1, 2, 3, 4, 5, 6, 8, 10, 4, 4)):
+        n = int(rng.integers(30000, 50000))
+        kind = rng.random(n)
+        body = rng.integers(0x40, 0x80, size=n).astype(np.uint8)                                   # DIFF
+        body = np.where(kind < 0.15, rng.integers(0x80, 0xc0, size=n), body).astype(np.uint8)     # LUMA op bytes (the byte behind is whatever comes)
+        body = np.where(kind > 0.985, 0xfe + (rng.random(n) < 0.3), body).astype(np.uint8)        # RGB / RGBA literals
+        body = np.where((kind > 0.97) & (kind <= 0.985), rng.integers(0xc0, 0xc4, size=n), body).astype(np.uint8)   # runs of 1..4
+        idx = rng.random(n) < per64 / 64.0
+        if k >= 8:   # INDEX ops in pairs and triples: one INDEX op's pixel is the next one's "most recent writer of my slot"
+            idx = idx | np.roll(idx, 1) | (np.roll(idx, 2) & (rng.random(n) < 0.5))
+        body = np.where(idx, rng.integers(0, 64 if k != 9 else 6, size=n), body).astype(np.uint8)
+        hdr_ch = (4, 3)[k & 1]
+        streams.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([hdr_ch, 0]) + body.tobytes() + bytes(7) + b"\x01")
+    slot = max(len(s) for s in streams) + 32
+    buf = np.zeros((len(streams), slot), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    dev = torch.from_numpy(buf).cuda()
+    for oc in (4, 3):
+        wants = [o.decode(s, oc)[0] for s in streams]
+        assert all(x is not None for x in wants)
+        dec = sq.DecodePlan(dev, [len(s) for s in streams], w, h, oc)
+        dec.launch()
+        res = dec.results()
+        out = dec.out.cpu().numpy()
+        for i, want in enumerate(wants):
+            assert res["status"][i] == 0 and res["qoi_compat"][i] == 1, (oc, i)
+            assert out[i].tobytes() == want.tobytes(), (oc, i)
+        dec.close()
+
+
 def test_speculative_qoi_route_finds_stale_index_entries(sq, orc, monkeypatch):
     """The speculative chip-wide QOI-compat decode (decode_qoi_kernel<8, SPEC> + dq_compare_kernel + dq_verify_kernel) guesses the
     colour index in front of every workgroup's range from the 4 KiB before it.  Streams built so that the guess is wrong in exactly

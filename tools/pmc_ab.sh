@@ -14,5 +14,5 @@ for v in $vs; do
   rocprofv3 --output-format csv --pmc $SQ3 -d $out/pmc3_${tag}_$v -o run -- python3 tools/prof_kernels.py --iters 2 "$@" > /dev/null 2>&1 || true
   python3 tools/pmc_table.py "$out/pmc1_${tag}_$v/**/*counter_collection.csv" "$out/pmc2_${tag}_$v/**/*counter_collection.csv" "$out/pmc3_${tag}_$v/**/*counter_collection.csv" > $out/${tag}_${v}_pmc.txt
   find $out/prof_${tag}_$v -name "*kernel_stats.csv" -exec cp {} $out/${tag}_${v}_kernel_stats.csv \;
-  echo "== $v"; grep -A30 "decode_wave_kernel" $out/${tag}_${v}_pmc.txt | head -32
+  echo "== $v"; (grep -A30 "decode_wave_kernel" $out/${tag}_${v}_pmc.txt || true) | head -32
 done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch only the product kernels on the headline batch (for rocprofv3 --pmc passes).
     python tools/prof_kernels.py [--images 256] [--iters 3] [--what encode|decode|both] [--qoi 0|1]"""
-import argparse, os, sys
+import argparse, os, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import seqoia_amd as sq
@@ -27,5 +27,6 @@ if a.what in ("decode", "both"):
     dec = sq.DecodePlan(enc.out, res["len"], a.size, a.size, a.out_channels)
     dec.launch(); dres = dec.results()
     assert (dres["status"] == 0).all()
-    assert torch.equal(dec.out[..., :min(a.channels, a.out_channels)], px[..., :min(a.channels, a.out_channels)])
+    if not os.environ.get("SQOA_PROF_NOCHECK"):   # (ablation builds -- stores or the serial part compiled out -- give wrong pixels on purpose)
+        assert torch.equal(dec.out[..., :min(a.channels, a.out_channels)], px[..., :min(a.channels, a.out_channels)])
     print("decode ms/launch", dec.time(a.iters) / a.iters, "Mpx/s", a.images * a.size * a.size / (dec.time(a.iters) / a.iters) / 1e3)
