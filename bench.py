@@ -744,7 +744,7 @@ def run_rank(args):
         "in_step_ms": round(enc_step_ms, 4),   # the same launch inside the encode -> decode step (median): what `value` is made of
     }, enc_pmc)
     roof_dec = pmc_fields({
-        "kernel": dec_pmc.get("kernel", "sqoa::bal::decode_bal_kernel<8, 16>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "kernel": dec_pmc.get("kernel", "sqoa::bal::decode_bal_kernel<8, 16, false>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
         "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
         "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS, 4),   # all of its bytes are streaming traffic

@@ -154,7 +154,8 @@ int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 
 /* Wait for the plan's most recent launch and copy the n results to host memory.  This call is what makes a launch's statuses and
  * lengths FINAL: a decode plan launches two more kernels behind its wave decoder (QOI-compat streams, mono streams, 1- / 2-channel
- * output, SQOA_OP_REF) until a launch's rows, read here in full (n = all jobs), show that no job needed them; from then on a launch
+ * output, SQOA_OP_REF; behind the balanced kernel a third in front of them, for streams with more op starts in a 1024-byte chunk than
+ * that kernel has slots) until a launch's rows, read here in full (n = all jobs), show that no job needed them; from then on a launch
  * leaves them out (two launches, ~9 us: a fifth of a plan of 4096 small icons), and if a later launch's rows come back
  * SQOA_HIP_ST_SLOWPATH -- other streams in the same buffers --, this call runs the two kernels before it returns the rows.  A caller
  * that consumes a decode plan's pixels on its own stream without asking for the results (graph replay) sees, for such a stream,

@@ -524,6 +524,7 @@ __global__ __launch_bounds__(128) void decode_fallback_kernel(const sqoa_hip_job
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape,
                                               sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode_retry(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
 
 extern "C" hipError_t sqoa_launch_decode_qoi_spec(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const void* d_images, int n_images,
                                                   const void* d_wgs, int n_wgs, const void* d_tab, const void* d_flags, void* d_qstate, unsigned per,
@@ -534,10 +535,15 @@ extern "C" hipError_t sqoa_launch_decode_passes(const sqoa_hip_job* d_jobs, sqoa
 // The kernels behind the wave decoder, over every job of the plan: what it marked SQOA_HIP_ST_SLOWPATH goes to the chunk-parallel QOI-compat
 // kernel (colour streams to 3 / 4 channels) and whatever that leaves marked (mono, 1- / 2-channel output, SQOA_OP_REF) to the fallback kernel; a
 // job that is not marked costs each of them one scalar load.
-extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {
+extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int retry, sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    // (`retry`: the launch in front was the balanced kernel, which hands on a stream with more op starts in a chunk than it has slots: the wave
+    // decoder first, over the streams so marked)
+    if (retry) e = sqoa_launch_decode_retry(d_jobs, d_ids, n, small, d_results, stream);
+    if (e != hipSuccess) return e;
 #if !defined(SQOA_QDEC) || SQOA_QDEC
-    hipError_t e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
+    e = sqoa_launch_decode_qoi(d_jobs, d_ids, n, small, d_results, stream);
     if (e != hipSuccess) return e;
 #endif
     hipLaunchKernelGGL(sqoa::decode_fallback_kernel, dim3(n), dim3(128), 0, stream, d_jobs, d_ids, d_results, 1);
@@ -577,5 +583,5 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (n_b > 0 && b_launched && join_event) e = hipStreamWaitEvent(stream, (hipEvent_t)join_event, 0);
     if (e != hipSuccess) return e;
     if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
-    return sqoa_launch_decode_standby(d_jobs, d_ids, n, small, d_results, stream);
+    return sqoa_launch_decode_standby(d_jobs, d_ids, n, small, ((shape | (n_b > 0 ? shape_b : 0)) & 8) ? 1 : 0, d_results, stream);
 }

@@ -95,7 +95,9 @@ SQOA_DEV Xf wave_xf_scan(Xf T BHLP) {
     return T;
 }
 
-template <int W, int LB>
+// RGB: the instance that also takes jobs to three channels (lists of mixed output formats; the plan's shape bit 4) -- the instance for lists
+// the host knows to be four-channel throughout carries none of that code (1.6 VALU + 1.8 scalar instructions per 64 pixels on the headline batch)
+template <int W, int LB, bool RGB = false>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_bal_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                                                     const int* __restrict__ job_ids,
                                                                                                     sqoa_hip_result* __restrict__ results) {
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     __shared__ unsigned long long s_pos[W];
     __shared__ unsigned long long s_px[W];
     __shared__ uint32_t s_path;  // 1 = decoded here, 2 = refused / left to the other kernels
+    __shared__ uint32_t s_oc;                      // output channels of the job: 3 or 4 (the header check)
 
     SQOA_PLACEMENT_PAD();
     const int lane = lane_id();
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t oc = job.desc.channels ? job.desc.channels : (hc < 3 ? 1u : 3u) + ((hc & 1u) ? 0u : 1u);
             if ((unsigned long long)hw * hh * oc > job.dst_cap) { res->status = SQOA_HIP_ST_OVERFLOW; path = 2; }
             else if (hc < 3 || q || oc < 3) { res->status = SQOA_HIP_ST_SLOWPATH; path = 2; }   // mono, QOI-compat, 1 / 2 channels out: the kernels behind
-            else if (oc != 4 || (job.dst & 3ull)) { res->status = SQOA_HIP_ST_INTERNAL; path = 2; }   // (the plan launches this kernel for four channels to dword-aligned addresses only)
+            else if (!((RGB && oc == 3) || (oc == 4 && !(job.dst & 3ull)))) { res->status = SQOA_HIP_ST_INTERNAL; path = 2; }   // (the plan launches this kernel for three channels, and for four to dword-aligned addresses, only)
+            s_oc = oc;
         }
         s_path = path;
     }
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t hw = (uint32_t)src[4] << 24 | (uint32_t)src[5] << 16 | (uint32_t)src[6] << 8 | src[7];
     const uint32_t hh = (uint32_t)src[8] << 24 | (uint32_t)src[9] << 16 | (uint32_t)src[10] << 8 | src[11];
     const uint32_t N = bcast_first(hw * hh);
-    constexpr int oc = 4;   // output channels (the header check above)
+    const uint32_t oc = RGB ? bcast_first(s_oc) : 4u;   // output channels: 4 (to a dword-aligned address) or 3 (the header check above)
+    const bool oc3 = RGB && oc == 3u;
     // Streams packed back to back (sqoa_hip_pack) start at any byte address: all stream offsets below are relative to the
     // dword-aligned address at or in front of the stream; the `soff` bytes in front of it are loaded but never looked at.
     const uint32_t soff = (uint32_t)(job.src & 3ull);
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     typedef __attribute__((address_space(1))) u32x4_una* gptr128u;
                     uint32_t lane;   // (opaque: see load_chunk)
                     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-                    {
+                    if (!oc3) {
                         for (uint32_t x0 = 0; x0 < n; x0 += 256u) {
                             const uint32_t x = x0 + 4u * lane;
                             gptr32 o = (gptr32)out + pos_in + wb + x;
@@ -567,6 +572,25 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 o[0] = pix[x];
                                 if (x + 1u < n) o[1] = pix[x + 1];
                                 if (x + 2u < n) o[2] = pix[x + 2];
+                            }
+                        }
+                    } else {
+                        // three channels: a lane's four pixels are twelve bytes -- r g b r | g b r g | b r g b -- at a byte address that is
+                        // whatever three times the pixel index makes it (one 12-byte store, as decode_wave_kernel's position-major path does)
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                        typedef u32x3 u32x3_una __attribute__((aligned(1)));
+                        typedef __attribute__((address_space(1))) u32x3_una* gptr96u;
+                        for (uint32_t x0 = 0; x0 < n; x0 += 256u) {
+                            const uint32_t x = x0 + 4u * lane;
+                            gptr8 o = out + ((size_t)pos_in + wb + x) * 3u;
+                            if (x + 4u <= n) {
+                                const u32x4 v = *reinterpret_cast<const u32x4*>(pix + x);
+                                *(gptr96u)o = u32x3{__builtin_amdgcn_perm(v.y, v.x, 0x04020100u), __builtin_amdgcn_perm(v.z, v.y, 0x05040201u),
+                                                    __builtin_amdgcn_perm(v.w, v.z, 0x06050402u)};
+                            } else if (x < n) {
+                                put_pixel<3>(o, 0, pix[x]);
+                                if (x + 1u < n) put_pixel<3>(o, 1, pix[x + 1]);
+                                if (x + 2u < n) put_pixel<3>(o, 2, pix[x + 2]);
                             }
                         }
                     }
@@ -638,6 +662,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             const uint32_t c1 = cnt < room ? cnt : room;
                             const uint32_t mm = (m & CL_MASK) | ((c1 < 2u ? c1 : 2u) << CL_BITS);
                             const uint32_t off = lane_off + ((m & CL_MASK) << 2);
+                            if (!oc3)
                             asm volatile(
                                 "v_cmpx_lt_u32_e32 vcc, %[c1], %[m]\n\t"           // a pixel
                                 "global_store_dword %[off], %[v], %[base]\n\t"
@@ -646,6 +671,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                                 "s_mov_b64 exec, %[ex]\n\t"
                                 "s_nop 4"
                                 :: [m] "v"(mm), [off] "v"(off), [v] "v"(val[i]), [base] "s"(obase), [ex] "s"(exec_in), [c1] "n"(CL_MASK), [c2] "n"(2u * CL_MASK + 1u) : "memory", "vcc");
+                            else {   // (three channels: byte stores; not a path to be fast on)
+                                if (c1 >= 1u) put_pixel<3>(out, P, val[i]);
+                                if (c1 >= 2u) put_pixel<3>(out, P + 1u, val[i]);
+                            }
                             const bool isrun = c1 > 2u;
                             const unsigned long long rm = __ballot(isrun);
                             const uint32_t rk = nruns + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
@@ -656,7 +685,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                         __builtin_amdgcn_wave_barrier();
                         for (uint32_t r = 0; r < nruns; ++r) {
                             const uint32_t rp = bcast_first(pix[r]), rc = bcast_first(pix[256 + r]), rv = bcast_first(pix[512 + r]);
-                            for (uint32_t t = (uint32_t)lane; t < rc; t += 64u) ((gptr32)out)[rp + t] = rv;
+                            if (!oc3) for (uint32_t t = (uint32_t)lane; t < rc; t += 64u) ((gptr32)out)[rp + t] = rv;
+                            else fill_pixels<3>(out, rp, rc, rv, lane);
                         }
                         __builtin_amdgcn_wave_barrier();
                     };
@@ -671,7 +701,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #endif
         if (last_chunk) {  // stream exhausted: the last pixel repeats (seqoia.h:726)
             if (pos_out < N) {
-                fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                if (!oc3) fill_pixels<4>(out, pos_out, N - pos_out, exit_v, lane);
+                else fill_pixels<3>(out, pos_out, N - pos_out, exit_v, lane);
             }
             if (lane == 0) res->len = (int)(N * (uint32_t)oc);
         }
@@ -720,8 +751,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
 // One workgroup per stream, the balanced kernel (see the file comment): the plan's choice for plans of large streams that go to four
 // channels (sqoa_runtime.hip; SQOA_HIP_DEC_BAL = 0 / 1 forces it).
-extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, sqoa_hip_result* d_results, hipStream_t stream) {
+extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int rgb, sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sqoa::bal::decode_bal_kernel<8, SQOA_BAL_LB>), dim3(n), dim3(8 * 64), 0, stream, d_jobs, d_ids, d_results);
+    if (rgb) hipLaunchKernelGGL((sqoa::bal::decode_bal_kernel<8, SQOA_BAL_LB, true>), dim3(n), dim3(8 * 64), 0, stream, d_jobs, d_ids, d_results);
+    else hipLaunchKernelGGL((sqoa::bal::decode_bal_kernel<8, SQOA_BAL_LB, false>), dim3(n), dim3(8 * 64), 0, stream, d_jobs, d_ids, d_results);
     return hipGetLastError();
 }

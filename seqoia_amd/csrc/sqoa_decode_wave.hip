@@ -311,6 +311,12 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
     }
     const sqoa_hip_job job = jobs[jid];
     sqoa_hip_result* res = &results[jid];
+    // MODE 0 launched as the RETRY behind the balanced kernel (dp_per = 1; sqoa_launch_decode_standby): only the streams that kernel handed
+    // on -- a chunk with more op starts than its 512 slots: a stretch of two-byte ops with a one-byte op in it, BIGRUN after BIGRUN; this
+    // kernel's walk takes those along (DEC_R below) -- start again here, from their first byte; the others cost a workgroup one scalar load.
+    // (Streams this kernel hands on in turn -- SQOA_OP_REF, mono, QOI-compat -- are marked as in a first launch, for the kernels behind.)
+    const bool retry = MODE == 0 && dp_per == 1u;
+    if (retry && __builtin_amdgcn_readfirstlane(res->status) != SQOA_HIP_ST_SLOWPATH) return;
     gcptr8 src = (gcptr8)job.src;
     gptr8 out = (gptr8)job.dst;
     const uint32_t size = job.src_size;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
         res->len = 0; res->status = SQOA_HIP_ST_OK;   // the row as every launch must find it: nobody else has touched it yet (sqoa_runtime.hip, plan_enqueue)
         res->desc.width = hw; res->desc.height = hh; res->desc.channels = (uint8_t)hc;
         res->desc.colorspace = (uint8_t)hs; res->desc.qoi_compat = (uint8_t)q;
-        row_mark_standby(res, 0);
+        row_mark_standby(res, retry ? 1 : 0);   // (a job the retry takes: the plan keeps launching the kernels behind its first one)
         const bool ok = !(hw == 0 || hh == 0 || hc < 1 || hc > 6 || hs > 1 || !(magic == 0x716f6966u || magic == 0x53716f61u) ||
                           (magic == 0x716f6966u && !q) || hh >= 400000000u / hw);
         uint32_t path = 1;
@@ -1031,11 +1037,11 @@ __global__ __launch_bounds__(W * 64) SQOA_DEC_WPE_ATTR void decode_wave_kernel(c
 // 24 % more issue-stall cycles: profiles/r04_a_photo_rgb_*).
 // `shape` bit 3: the BALANCED kernel (sqoa_decode_bal.hip: a lane owns consecutive ops, not consecutive bytes; 1024-byte chunks) -- the
 // plan's choice where it would pick the wide shape for large streams.
-extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode_bal(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int rgb, sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape,
                                               sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (shape & 8) return sqoa_launch_decode_bal(d_jobs, d_ids, n, d_results, stream);
+    if (shape & 8) return sqoa_launch_decode_bal(d_jobs, d_ids, n, (shape & 16) ? 1 : 0, d_results, stream);   // (bit 4: the list holds jobs to three channels)
 #ifndef SQOA_DEC_W
 #define SQOA_DEC_W 8
 #endif
@@ -1056,6 +1062,16 @@ extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const 
     else if (wide) SQOA_DEC_LAUNCH(W, LB0, false);
     else SQOA_DEC_LAUNCH(W, LB, false);
 #undef SQOA_DEC_LAUNCH
+    return hipGetLastError();
+}
+
+// The retry behind the balanced kernel: decode_wave_kernel, eight stream bytes per lane, over the same list -- a workgroup whose stream is not
+// marked SQOA_HIP_ST_SLOWPATH leaves at once (see the kernel).
+extern "C" hipError_t sqoa_launch_decode_retry(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    constexpr int W = SQOA_DEC_W, WS = SQOA_DEC_W_SMALL, LB = SQOA_DEC_LB;
+    if (small) hipLaunchKernelGGL((sqoa::decode_wave_kernel<WS, 0, LB, false>), dim3(n), dim3(WS * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 1u, 0u);
+    else hipLaunchKernelGGL((sqoa::decode_wave_kernel<W, 0, LB, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, nullptr, nullptr, nullptr, nullptr, 1u, 0u);
     return hipGetLastError();
 }
 

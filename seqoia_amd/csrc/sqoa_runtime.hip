@@ -20,7 +20,7 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
 extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                                sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int retry, sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
@@ -44,6 +44,14 @@ extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const 
 #endif
 // ... and where the others will take the balanced kernel (sqoa_decode_bal.hip; round 5: 1024 streams of 1 Mpixel 2.59 ms chained, 5.96 in
 // three passes; 256 streams, one per compute unit, 1.37 against 1.56): the passes cost 2.3 x, a lone stream 2.3 x 256 x 1.37 / 1.56
+// Lists that go mostly to THREE channels: the balanced kernel takes three-channel jobs (12-byte stores), but which kernel wins is a matter of
+// content the plan cannot see -- class mixed to three channels 3.10 -> 2.25 ms with it, class photo 2.78 -> 3.19 (ops of even length: LDS bank
+// conflicts of the balanced walk's table look-ups; to four channels the same: 2.71 against 3.19, and class mixed 2.98 against 2.57).  Photographs
+// are what three-channel lists usually hold: they stay with decode_wave_kernel unless SQOA_HIP_DEC_BAL=1 says otherwise; three-channel jobs
+// inside a list that takes the balanced kernel for its four-channel bytes ride along in the one launch (BASELINE configs[4]: 10.50 -> 10.34 ms).
+#ifndef SQOA_DEC_BAL_RGB
+#define SQOA_DEC_BAL_RGB 0
+#endif
 #ifndef SQOA_DP_COST_BAL
 #define SQOA_DP_COST_BAL 2.3
 #define SQOA_DP_SOLO_BAL 520.0
@@ -448,7 +456,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         // faster with a compute unit to itself than the kernel the model's constants were fitted to: tools/time_few.py, 256 streams of
         // 1 Mpixel 1.37 ms chained against 1.56 in three passes, 1024 of them 2.59 against 5.96)
         bool bal_cand = !ids_a.empty() && bytes / ids_a.size() >= (12u << 10) && !p->small;
-        for (int i : ids_a) if (jobs[i].desc.channels != 4 || (jobs[i].dst & 3ull)) bal_cand = false;
+        for (int i : ids_a) if (!(jobs[i].desc.channels == 3 || (jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull)))) bal_cand = false;
         if (const char* kb = getenv("SQOA_HIP_DEC_BAL")) if (kb[0] == '0') bal_cand = false;
         int rc = decode_route(sizes.data(), (int)sizes.size(), cus, mode, bal_cand ? SQOA_DP_COST_BAL : SQOA_DP_COST, bal_cand ? SQOA_DP_SOLO_BAL : SQOA_DP_SOLO, order.data(), &n_multi);
         if (rc) return rc;
@@ -473,17 +481,19 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             const char* kw = getenv("SQOA_HIP_DEC_WIDE");
             const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
             const char* kb = getenv("SQOA_HIP_DEC_BAL");
-            auto four = [&](int i) { return jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull); };   // what the balanced kernel takes
+            // what the balanced kernel takes: four channels to a dword-aligned address, or three (round 5: 12-byte stores at any byte address)
+            auto four = [&](int i) { return jobs[i].desc.channels == 3 || (jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull)); };
             auto shape_of = [&](size_t a, size_t b) -> int {
                 if (a >= b) return 0;
                 unsigned long long by = 0, by4 = 0, px = 0;
-                bool shaped = true, all4 = true;
+                bool shaped = true, all4 = true, any3 = false;
                 for (size_t k = a; k < b; ++k) {
                     const sqoa_hip_job& j = jobs[ids_a[k]];
                     by += j.src_size;
                     px += (unsigned long long)j.desc.width * j.desc.height;
                     if (j.desc.channels == 4) by4 += j.src_size;
                     if (!four(ids_a[k])) all4 = false;
+                    if (j.desc.channels != 4) any3 = true;
                     if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
                 }
                 const bool roomy = by / (b - a) >= (12u << 10);
@@ -493,10 +503,10 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
                 //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
                 //    -- a kernel for four channels to dword-aligned addresses only, so only for lists whose every job is that
-                int bal = wide && !sweep && !p->small;
+                int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !p->small;
                 if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
                 bal = bal && all4;
-                return p->small | wide << 1 | sweep << 2 | bal << 3;
+                return p->small | wide << 1 | sweep << 2 | bal << 3 | (bal && any3 ? 1 : 0) << 4;   // (bit 4: the balanced kernel's instance that takes three-channel jobs)
             };
             p->shape = shape_of(c0, ids_a.size());
             p->n_chain_b = 0; p->shape_b = 0;
@@ -782,7 +792,7 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
         }
         if (p->skipped_last && slow) {
             // the launch left the kernels behind the wave decoder out and a stream needed them after all: now, then the rows once more
-            HIP_TRY(sqoa_launch_decode_standby(p->d_jobs, p->d_ids, p->n_sqoa, p->small, p->d_results, p->stream), SQOA_HIP_ELAUNCH);
+            HIP_TRY(sqoa_launch_decode_standby(p->d_jobs, p->d_ids, p->n_sqoa, p->small, ((p->shape | (p->n_chain_b > 0 ? p->shape_b : 0)) & 8) ? 1 : 0, p->d_results, p->stream), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
             p->lazy_skip = false; p->skipped_last = false;

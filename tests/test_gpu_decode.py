@@ -746,6 +746,48 @@ def _qoi_hash(r, g, b, a=255):
     return (r * 3 + g * 5 + b * 7 + a * 11) % 64   # seqoia.h:785-787 (qoi_compat)
 
 
+@pytest.mark.parametrize("oc", [4, 3])
+def test_streams_with_more_op_starts_than_the_balanced_kernel_has_slots(sq, orc, monkeypatch, oc):
+    """The balanced kernel has 512 op slots per 1024-byte chunk and hands on a stream whose chunk holds more starts than that -- which the
+    reference's own encoder writes for plain content: a ramp is two-byte LUMA ops throughout, and the one-byte RUN in front of them makes
+    513 starts of the first chunk; a flat half below a noisy half is BIGRUN after BIGRUN, every byte a start.  Round 5 found such streams
+    at 2 Mpixel/s in the exact decoder (515 ms for a launch of 256 ramps): now the wave decoder takes them in a retry behind the balanced
+    kernel (sqoa_launch_decode_standby).  The plan's own choice of kernel for a workgroup per stream (the three chip-wide passes, which a
+    plan of 64 streams would take, switched off): the reference's pixels, in a millisecond range -- on the first launch (repaired by
+    sqoa_hip_plan_results) and on the relaunches (the kernels behind the first one stay in the launch)."""
+    import torch
+
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", "0")
+    n, s = 64, 512
+    x = torch.arange(s, device="cuda", dtype=torch.int32)
+    row = (x & 255).to(torch.uint8)
+    ramp = torch.stack([row, row, row, torch.full_like(row, 255)], dim=-1).expand(n // 2, s, s, 4).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    half = torch.randint(0, 256, (n // 2, s, s, 4), device="cuda", dtype=torch.uint8, generator=g)
+    half[..., 3] = 255
+    half[:, s // 2 :, :, :3] = 200   # (131 072 flat pixels: 256 BIGRUN bytes on end)
+    px = torch.cat([ramp, half], dim=0)
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    enc.launch()
+    res = enc.results()
+    assert (res["status"] == 0).all()
+    streams = enc.streams()
+    o = orc.best()
+    dec = sq.DecodePlan(enc.out, res["len"], s, s, oc)
+    for launch in range(3):
+        dec.launch()
+        r = dec.results()
+        assert (r["status"] == 0).all() and (r["len"] == s * s * oc).all(), (launch, r["status"][:4])
+        assert torch.equal(dec.out[..., :3], px[..., :3]) and (oc == 3 or bool((dec.out[..., 3] == 255).all())), launch
+    for i in (0, n // 2, n - 1):
+        assert dec.out[i].cpu().numpy().tobytes() == o.decode(streams[i], oc)[0].tobytes(), i
+    dec.time(2)
+    ms = min(dec.time(3) / 3 for _ in range(3))
+    assert ms < 5.0, ms   # (16.8 Mpixel: the balanced kernel as far as it gets + the retry; the exact decoder took 130 ms for these)
+    dec.close()
+    enc.close()
+
+
 def test_qoi_groups_of_few_index_ops_match_oracle(sq, orc, route):
     """The resolver settles a 64-op group that holds up to SQOA_QDEC_SEQ_MAX (4) INDEX ops one op after the other in registers, and a group with
     more by the fixed point: bodies whose INDEX ops are SPARSE, at densities from one in 64 ops to ten in 64 -- groups on both

@@ -9,7 +9,7 @@ import statistics as st
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r.get("Kind", "KERNEL_DISPATCH") == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-heads = {"encode": "sqoa::encode_kernel<8, false>", "decode_bal": "sqoa::bal::decode_bal_kernel<8, 16>", "decode_wave": "sqoa::decode_wave_kernel<8, 0"}
+heads = {"encode": "sqoa::encode_kernel<8, false>", "decode_bal": "sqoa::bal::decode_bal_kernel<8, 16", "decode_wave": "sqoa::decode_wave_kernel<8, 0"}
 out = {}
 def q(x, p):
     x = sorted(x); return x[min(len(x) - 1, int(p * len(x)))]

@@ -37,7 +37,7 @@ out = {"note": f"rocprofv3 --pmc passes (one counter group per pass: HBM bytes, 
                f"Full table: profiles/{sys.argv[2]}_pmc_summary.txt, profiles/{sys.argv[2]}_kernel_stats.csv (tools/profile_round.sh {sys.argv[2]})",
        "csrc_sha256": h.hexdigest(), "images": out_images, "size": size, "kernels": {}}
 groups = out_images * size * size / 64.0
-for name, pres in (("encode", ("sqoa::encode_kernel<8, false>",)), ("decode", ("sqoa::bal::decode_bal_kernel<8, 16>", "sqoa::decode_wave_kernel<8, 0"))):
+for name, pres in (("encode", ("sqoa::encode_kernel<8, false>",)), ("decode", ("sqoa::bal::decode_bal_kernel<8, 16", "sqoa::decode_wave_kernel<8, 0"))):
     kname, k, pre = None, None, None
     for pre in pres:   # (the decoder the plan picked for the headline batch: the first of these that ran)
         kname, k = pick(kern, pre)
