@@ -67,6 +67,9 @@ SQOA_DEV void static_for(F&& f) {
         if (f(std::integral_constant<int, I>{})) static_for<I + 1, N>(f);
     }
 }
+#ifndef SQOA_BAL_RUN_IN_SFX   // 2: the fused RUN's count from the suffix table (entries four bytes apart) instead of a second look-up in the op table; 0: as before
+#define SQOA_BAL_RUN_IN_SFX 2
+#endif
 #ifndef SQOA_BAL_HL_VGPR   // the SWAR constants of the packed-byte adds in two VGPRs: as literals the compiler parks them in SGPRs, and an SGPR operand makes a fast-class instruction a slow one
 #define SQOA_BAL_HL_VGPR 0
 #endif
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     // op byte -> {info, absolute-channel mask, LUMA r/b base, LUMA g | nibble mask} (decode_wave_kernel's table)
     //   info: len (3) | (len*8 - 4) (6) << 3 | pixels (10) << 9 | REF (1) << 20 | pixels if the byte is a RUN / BIGRUN (10) << 21
     __shared__ __attribute__((aligned(16))) u32x4 s_optab[256];
-    __shared__ uint32_t s_sfx[256];    // byte -> ALPHA suffix: delta << 24 | 8 (shift) | 1 (length), else 0
+    __shared__ uint32_t s_sfx[256];    // byte -> ALPHA suffix: delta << 24 | 8 (shift) | 1 (length); RUN / BIGRUN: pixels << 8; else 0
 #ifndef SQOA_BAL_LIST32   // the list's entries as dwords: two lanes' ds_write_b16 into one dword collide (2.881 -> 2.868 ms)
 #define SQOA_BAL_LIST32 1
 #endif
@@ -182,12 +185,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t cnt = (is_abs || is_luma) ? 1u : (b0 == 0xfdu ? 512u : (b0 & 0x3fu) + 1u);
         const uint32_t vg = (b0 & 0x3fu) - 32u;
         u32x4 e;
-        e.x = len | (len * 8u - 4u) << 3 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
+        e.x = len | (len * 8u - (SQOA_BAL_RUN_IN_SFX == 2 ? 2u : 4u)) << 3 | cnt << 9 | (b0 < 0x60u ? 1u << 20 : 0u) | (is_run ? cnt << 21 : 0u);
         e.y = is_abs ? (b0 == 0xffu ? 0xffffffffu : 0x00ffffffu) : 0u;
         e.z = is_luma ? (((vg - 8u) & 0xffu) | ((vg - 8u) & 0xffu) << 16) : 0u;
         e.w = is_luma ? ((vg & 0xffu) << 8 | 0x000f000fu) : 0u;
         s_optab[b0] = e;
-        s_sfx[b0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 9u) : 0u;
+        s_sfx[b0] = is_sfx ? ((((b0 & 31u) - 16u) & 0xffu) << 24 | 9u) : (is_run ? cnt << 8 : 0u);
     }
     __syncthreads();
     if (s_path != 1) return;
@@ -474,12 +477,26 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // byte after the op (seqoia.h:777-783): an ALPHA suffix belongs to the op.  w1 = stream >> (8 * len - 4).
                     const unsigned long long qq = (unsigned long long)hi << 32 | lo;
                     const uint32_t w1 = (uint32_t)(qq >> ((e.x >> 3) & 63u));
+#if SQOA_BAL_RUN_IN_SFX == 2
+                    // (w1 = stream >> (8 * len - 2): the byte behind the op times four in bits 2..9 -- the suffix table's byte offset in ONE instruction)
+                    const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + (w1 & 0x3fcu));
+#else
                     const uint32_t se = *(lcptr32)(uintptr_t)(sfx_addr + ((w1 >> 2) & 0x3fcu));
+#endif
                     const uint32_t has8 = se & 8u, da24 = se & 0xff000000u;
                     [[maybe_unused]] const uint32_t adv = len + (se & 1u);
                     // a RUN right behind the op (and its suffix) repeats the pixel this op produces: taken along, as the parser did (state G)
+#if SQOA_BAL_RUN_IN_SFX == 2
+                    // (the RUN count of the byte behind op and suffix from the suffix table's entries, four bytes apart -- the op table's second
+                    // look-up asked for one dword of 16-byte entries: eight LDS banks for 64 lanes, a 4-way conflict in each half of the wave
+                    // wherever the lanes' next bytes differ: class photo 3.19 -> 3.05 ms, the headline batch 2.573 -> 2.555, configs[4]'s shard 10.28 -> 10.13.
+                    // Skipping the look-up by a vote of the wave where no lane has a suffix: photo 2.96, but the headline batch 2.61 -- its waves have.)
+                    const uint32_t w2 = w1 >> has8;
+                    uint32_t extra = (*(lcptr32)(uintptr_t)(sfx_addr + (w2 & 0x3fcu)) >> 8) & 0x3ffu;          // 0 unless RUN / BIGRUN
+#else
                     const uint32_t w2 = w1 >> has8;
                     uint32_t extra = *(lcptr32)(uintptr_t)(optab_addr + (w2 & 0xff0u)) >> 21;               // 0 unless RUN / BIGRUN
+#endif
                     if (!IN) extra &= sra31(pos + adv - live_end);                                         // (a RUN past the chunk area does not exist)
                     cnt += extra;
                     const uint32_t bse = __builtin_amdgcn_alignbit(hi, lo, 8) + da24;                                 // RGB[A], seqoia.h:740-752
