@@ -14,7 +14,10 @@
 //      goes to a list in LDS at its rank.
 //   3. walk: the chunk's n ops are dealt out q = ceil(n / 64) consecutive ones per lane -- lane j starts at list[j q] -- and every
 //      lane decodes its q ops (table look-ups and mask arithmetic as in decode_wave_kernel): q iterations whatever the content, all
-//      lanes busy but the tail.  Chunks of more than 512 ops (never from the encoder at 3 bytes per op: crafted streams) go in pieces.
+//      lanes busy but the tail.  A chunk of more than 512 op starts (64 lanes x 8 record slots) is more than this kernel takes: the stream
+//      is marked SQOA_HIP_ST_SLOWPATH and decode_wave_kernel decodes it in the retry behind this launch (sqoa_launch_decode_standby) --
+//      and that is not crafted streams only: a ramp is two-byte LUMA ops throughout, 513 starts in its first chunk with the one-byte RUN
+//      in front; a flat region is BIGRUN after BIGRUN, every byte a start.
 //   4. scans, chain, stores: as there.
 //
 // Because ownership no longer follows the bytes, the per-op records (8 slots) bound the OPS per piece, not the bytes per lane: the
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t rinc = wave_incl_scan(n_lane);
         const uint32_t n_ops = bcast_lane(rinc, 63);
         // (more than 64 R walk iterations in a chunk: two starts are two bytes apart or more on average unless one-byte ops that nothing takes
-        // along follow each other -- SQOA_OP_REF bytes, which hand the stream over anyway.  Checked, not assumed.)
+        // along follow each other -- SQOA_OP_REF bytes, which hand the stream over anyway, but also RUN behind RUN (flat regions: BIGRUN bytes on
+        // end), and 512 two-byte ops plus ONE one-byte op are 513.  The stream goes to the retry behind this launch: the file's head.)
         if (n_ops > 64u * R) {   // (before the list is written: it has room for 64 R starts)
             if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
             return 0u;

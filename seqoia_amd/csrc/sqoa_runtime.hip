@@ -502,7 +502,8 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
                 //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
                 //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
-                //    -- a kernel for four channels to dword-aligned addresses only, so only for lists whose every job is that
+                //    -- a kernel for four channels to dword-aligned addresses and (its RGB instance, bit 4) for three channels, so only for lists
+                //    whose every job is one of the two; a list to three channels alone keeps the wave decoder (SQOA_DEC_BAL_RGB above)
                 int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !p->small;
                 if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
                 bal = bal && all4;
