@@ -33,11 +33,16 @@ $(OUT)/libsqoa_mi355x.so: $(OBJS)
 oracle:
 	$(MAKE) -s -C oracle
 
-TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x tools/bin/sqoabatch_mi355x
+TOOLS := tools/bin/sqoabench_mi355x tools/bin/sqoaconv_mi355x tools/bin/sqoabatch_mi355x tools/bin/lds_atomic_order
 tools: lib $(TOOLS)
 tools/bin/%: tools/%.c include/seqoia.h include/sqoa_hip.h
 	@mkdir -p tools/bin
 	$(CC) -std=gnu99 -O2 -Wall -Iinclude $< -o $@ -L$(OUT) -lsqoa_mi355x -lpthread -Wl,-rpath,'$$ORIGIN/../../$(OUT)'
+
+# the hardware property the QOI-compat encoder's probes rest on (sqoa_encode.hip, SQOA_ENC_Q_RTN): checked on the GPU box by tests/test_gpu_tools.py
+tools/bin/lds_atomic_order: tools/ubench/lds_atomic_order.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -O2 $< -o $@
 
 clean:
 	rm -rf $(BUILD) $(OUT)/*.so tools/bin

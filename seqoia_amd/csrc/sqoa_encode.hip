@@ -342,6 +342,9 @@ SQOA_DEV SwarGroup qoi_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uin
     return o;
 }
 
+#ifndef SQOA_ENC_Q_RTN   // QOI-compat L8 probes: the nearest lower lane on my slot from one ds_max_rtn_u32 (LDS applies an instruction's lanes in ascending order)
+#define SQOA_ENC_Q_RTN 2
+#endif
 #ifndef SQOA_ENC_Q_PIPE
 #define SQOA_ENC_Q_PIPE 1
 #endif
@@ -579,8 +582,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     constexpr int QW = QOI ? W : 1;
     __shared__ uint32_t s_tabw[QW][64];
     __shared__ uint32_t s_stamp[QW][64];
-    __shared__ unsigned long long s_last[QL8 ? W : 1][QL8 ? 64 : 1];   // L8 hot loop: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer
+    // L8 hot loop without SQOA_ENC_Q_RTN == 2: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer (with it: one row of zeros that
+    // the table hop of the row-layout path reads and writes back)
+    constexpr int QLW = QL8 ? (SQOA_ENC_Q_RTN == 2 ? 1 : W) : 1;
+    __shared__ unsigned long long s_last[QLW][QL8 ? 64 : 1];
     __shared__ unsigned long long s_smask[QW][64];
+    // L8 hot loop (SQOA_ENC_Q_RTN): per slot, the stamp (row number * 64 + lane + 1, growing for the wave's lifetime) of the last pixel that took it
+    __shared__ uint32_t s_pstamp[QL8 && SQOA_ENC_Q_RTN ? W : 1][QL8 && SQOA_ENC_Q_RTN ? 64 : 1];
+    // ... and (SQOA_ENC_Q_RTN == 2) its pixel: with the stamps the sub-tile's "last writer per slot" for the table hop, by plain writes
+    __shared__ uint32_t s_lastpx[QL8 && SQOA_ENC_Q_RTN == 2 ? W : 1][QL8 && SQOA_ENC_Q_RTN == 2 ? 64 : 1];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
     __shared__ uint32_t s_tabtag[2][W];
     // L8 path: run bytes of the 8 consecutive pixels a lane owns, by their 8 "repeats its predecessor" flags: byte j =
@@ -615,7 +625,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
     const lptr8 stage = (lptr8)s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
-    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QW][lane] = 0; }
+    if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QLW][lane] = 0; }
+    if (QL8 && SQOA_ENC_Q_RTN) s_pstamp[w % QW][lane] = 0;
+    [[maybe_unused]] uint32_t qrow64 = 0;   // (SQOA_ENC_Q_RTN: 64 x the rows this wave has probed)
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *(lptr_x4)(stage + i) = u32x4{0u, 0u, 0u, 0u};
     {
         for (uint32_t e8 = threadIdx.x; e8 < 256u; e8 += W * 64) {
@@ -759,9 +771,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     // QOI-compat, L8 hot loop (j > 0, sub-tiles follow): the colour index entering sub-tile j and the one leaving it.  `writers`
     // marks the sub-tile's last writer per slot (stamps) and puts their pixels into the table to be published; the slots the
     // sub-tile does not write are filled from the table the sub-tile in front published (composition by overwrite).
-    auto qoi_table_hop = [&](uint32_t j, bool, auto&& writers) {
+    auto qoi_table_hop = [&](uint32_t j, [[maybe_unused]] bool l8, auto&& writers) {
         if constexpr (QOI) {
-            unsigned long long* last = s_last[w % QW];
+            unsigned long long* last = s_last[w % QLW];
             uint32_t* pub = s_tabpub[(j / W) & 1][w % QW];
             writers(last);
             const uint32_t pp = ((j - 1) / W) & 1, pw = (j - 1) % W;
@@ -772,10 +784,16 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_QTAB_SLEEP);
             }
             const uint32_t tin = s_tabpub[pp][pw % QW][lane];
-            const unsigned long long e = last[lane];
-            pub[lane] = (uint32_t)(e >> 32) ? (uint32_t)e : tin;
-            s_tabw[w % QW][lane] = tin;
-            last[lane] = 0;
+            if (QL8 && SQOA_ENC_Q_RTN == 2 && l8) {
+                // (the slots this sub-tile wrote are the ones whose stamp is of this sub-tile; their pixel: the last plain write's)
+                pub[lane] = s_pstamp[w % QW][lane] > qrow64 ? s_lastpx[w % QW][lane] : tin;
+                s_tabw[w % QW][lane] = tin;
+            } else {
+                const unsigned long long e = last[lane];
+                pub[lane] = (uint32_t)(e >> 32) ? (uint32_t)e : tin;
+                s_tabw[w % QW][lane] = tin;
+                last[lane] = 0;
+            }
             if (lane == 0) __hip_atomic_store(&s_tabtag[(j / W) & 1][w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
@@ -1174,6 +1192,51 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     }
                 }
                 uint8_t* hit = s_hit[w];
+#if SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN == 2
+                // gfx950's LDS applies the lanes of ONE instruction that meet on an address in ascending lane order: of an atomic with return
+                // every lane gets what the lanes below it left, of a plain write the highest lane's value stays (tools/ubench/lds_atomic_order.hip:
+                // 8 x 10^8 of each over random, strided, clustered and single-address patterns with eight waves on the LDS, none out of order;
+                // tests/test_gpu_tools.py runs it on the box).  Two things follow (round 5):
+                //  * `ds_max_rtn_u32` of a stamp that grows with row and lane hands every lane the stamp of the nearest LOWER lane of its row
+                //    on its index slot (or an older row's: none) -- what the per-slot 64-bit lane masks took a ds_or_b64, a ds_read_b64, a
+                //    clear by the last writer and a dozen instructions of 64-bit mask arithmetic to find;
+                //  * "the sub-tile's last writer of every slot" -- what the table hop publishes before the incoming table is known -- is the
+                //    last plain ds_write_b32 of the pixel, row after row, and "did the sub-tile write the slot" is "its stamp is of this
+                //    sub-tile": eight b32 writes where there were eight ds_max_u64, nothing to clear.
+                // The atomics do not depend on the table: they are issued here, in front of the wait for the sub-tile before.
+                uint32_t ph[ENC_S], pprev[ENC_S];
+                qoi_table_hop(j, true, [&](unsigned long long*) {
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const uint32_t h = qoi_hash(rowpx[r]);
+                        ph[r] = h;
+                        pprev[r] = 0;
+                        if ((nebits >> r) & 1u) {
+                            pprev[r] = __hip_atomic_fetch_max(&s_pstamp[w][h], qrow64 + (uint32_t)(r * 64 + lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            s_lastpx[w][h] = rowpx[r];
+                        }
+                    }
+                });
+                {
+                    // the eight rows' probes: the slot's entry as the rows before left it (row r + 1's read travels with row r's ds_bpermute:
+                    // LDS keeps a wave's order, nothing is waited for between a row's table write and the next row's read)
+                    uint32_t pcand[ENC_S];
+                    pcand[0] = s_tabw[w][ph[0]];
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const bool ne = (nebits >> r) & 1u;
+                        const uint32_t rb = qrow64 + (uint32_t)(r * 64);
+                        const bool lower = pprev[r] > rb;                                  // a lower lane of THIS row took my slot
+                        const int from = lower ? (int)(pprev[r] - rb - 1u) : lane;
+                        const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)rowpx[r]);
+                        if (ne) s_tabw[w][ph[r]] = rowpx[r];                                // (of the lanes on one slot the highest stays: the row's last writer)
+                        if (r + 1 < ENC_S) pcand[r + 1] = s_tabw[w][ph[r + 1]];
+                        const uint32_t cand = lower ? near : pcand[r];
+                        hit[r * 64 + lane] = (uint8_t)((ne && cand == rowpx[r]) ? 0x80u | ph[r] : 0u);
+                    }
+                    qrow64 += (uint32_t)(ENC_S * 64);
+                }
+#else
                 qoi_table_hop(j, true, [&](unsigned long long* last) {
 #ifdef SQOA_DBG_Q_NOSTAMP
                     return;
@@ -1184,7 +1247,41 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     for (int r = 0; r < ENC_S; ++r)
                         if ((nebits >> r) & 1u) atomicMax(&last[qoi_hash(rowpx[r])], (unsigned long long)(r * 64 + lane + 1) << 32 | rowpx[r]);
                 });
-#if SQOA_ENC_Q_PIPE
+#if SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN
+                // The eight rows' probes with ONE atomic per row for "who of my row is on my slot" (round 5).  gfx950's LDS applies the lanes of
+                // one atomic instruction that meet on an address in ascending lane order, and of one plain write the highest lane's value stays
+                // (tools/ubench/lds_atomic_order.hip: 8 x 10^8 atomics over random, strided and single-address patterns with eight waves on the
+                // LDS, not one out of order; tests/test_gpu_tools.py runs it).  So `ds_max_rtn_u32` of a stamp that grows with row and lane hands
+                // every lane the stamp of the nearest LOWER lane of its row on its slot (or an older row's stamp: none) -- which the per-slot
+                // 64-bit lane masks took a ds_or_b64, a ds_read_b64, a clear by the last writer and a dozen instructions of 64-bit mask
+                // arithmetic to find -- and the row's table update is one ds_write_b32 by every lane that starts an op: the last one wins.
+                // Pipelined as before: row r's ds_bpermute travels with row r + 1's reads.
+                {
+                    uint32_t ph[ENC_S], pcand[ENC_S], pprev[ENC_S];
+                    auto probe_a = [&](int r) {   // my slot's entry as the rows before left it; my stamp into the slot, the stamp before mine out
+                        const uint32_t h = qoi_hash(rowpx[r]);
+                        ph[r] = h;
+                        pcand[r] = s_tabw[w][h];
+                        pprev[r] = 0;
+                        if ((nebits >> r) & 1u)
+                            pprev[r] = __hip_atomic_fetch_max(&s_pstamp[w][h], qrow64 + (uint32_t)(r * 64 + lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    };
+                    probe_a(0);
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const bool ne = (nebits >> r) & 1u;
+                        const uint32_t rb = qrow64 + (uint32_t)(r * 64);
+                        const bool lower = pprev[r] > rb;                                  // a lower lane of THIS row took my slot
+                        const int from = lower ? (int)(pprev[r] - rb - 1u) : lane;
+                        const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)rowpx[r]);
+                        if (ne) s_tabw[w][ph[r]] = rowpx[r];                                // (of the lanes on one slot the highest stays: the row's last writer)
+                        if (r + 1 < ENC_S) probe_a(r + 1);
+                        const uint32_t cand = lower ? near : pcand[r];
+                        hit[r * 64 + lane] = (uint8_t)((ne && cand == rowpx[r]) ? 0x80u | ph[r] : 0u);
+                    }
+                    qrow64 += (uint32_t)(ENC_S * 64);
+                }
+#elif SQOA_ENC_Q_PIPE
                 // The eight rows' probes, software-pipelined by hand.  Row r + 1 can only look at the table after row r has written it, but
                 // LDS executes a wave's instructions in order: nothing has to be WAITED for between row r's writes and row r + 1's reads.
                 // What a row does wait for is its own lane-mask word (who else of the row is on my slot); the write of the table entry
@@ -1226,6 +1323,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 }
 #else
                     hit[r * 64 + lane] = (uint8_t)qoi_probe_row(rowpx[r], (nebits >> r) & 1u, s_tabw[w], s_smask[w], lane, le_mask);
+#endif
 #endif
 #endif
                 const uint2 hv = *reinterpret_cast<const uint2*>(hit + 8 * lane);

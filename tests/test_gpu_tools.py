@@ -108,3 +108,19 @@ def test_bench_rank_path_with_two_ranks_on_the_card():
     assert out["n_gpus"] == 2 and "rehearsal" in out and out["scaling"] == "weak"
     assert out["config"]["encoded_bytes_check"] == out["config"]["encoded_bytes_total"] > 0
     assert out["value"] > 0 and out["steps"] == 2
+
+
+def test_lds_applies_the_lanes_of_an_atomic_in_ascending_order():
+    """The QOI-compat encoder's L8 probes (sqoa_encode.hip, SQOA_ENC_Q_RTN) take "the nearest lower lane of my row on my index slot" from ONE
+    `ds_max_rtn_u32` per row, and let the row's last writer of a slot win by plain `ds_write_b32`: both rest on the order in which gfx950's LDS
+    applies the lanes of one instruction that meet on an address -- ascending lane number.  tools/ubench/lds_atomic_order.hip puts 8 x 10^8
+    atomics and as many plain writes through random, strided, clustered and single-address patterns, eight waves to a workgroup's LDS, and
+    counts every lane whose returned value is not the stamp of the highest lower lane on its address, and every address whose final value
+    is not the highest lane's: all zero, or the encoder's output is not the reference's (which the parity tests would show as well)."""
+    exe = os.path.join(BIN, "lds_atomic_order")
+    assert os.path.exists(exe), "tools/bin/lds_atomic_order is built by `make tools`"
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+    lines = [l for l in out.splitlines() if l.startswith("pattern")]
+    assert len(lines) == 24, out
+    for l in lines:
+        assert "out of order 0," in l and l.rstrip().endswith("highest lane 0"), l
