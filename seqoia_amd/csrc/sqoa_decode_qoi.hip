@@ -61,6 +61,9 @@ namespace sqoa {
 #ifndef SQOA_QDEC_SEQ_MAX   // the resolver: groups of up to this many INDEX ops are settled one op after the other, in registers (round 5); 0: always the fixed point
 #define SQOA_QDEC_SEQ_MAX 4
 #endif
+#ifndef SQOA_QDEC_TABW   // the resolver's index update a plain write (the highest lane on a slot stays) instead of a stamped ds_max_u64
+#define SQOA_QDEC_TABW 1
+#endif
 #ifndef SQOA_QDEC_BAL   // the producers' walk balanced over the lanes (round 5)
 #define SQOA_QDEC_BAL 1
 #endif
@@ -293,8 +296,15 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     // seqoia.h:785-787 for the whole group: the last writer of a slot wins; and the pixels, for the producer's stores
                     auto commit = [&](uint32_t val, uint32_t hv) {
                         if (live) {
-                            __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // seqoia.h:785-787 for 64 ops at once: of the lanes of one LDS write that meet on a slot the HIGHEST stays (gfx950 applies
+                            // an instruction's lanes in ascending order: tools/ubench/lds_atomic_order.hip, run by the GPU tests), and a later
+                            // group's write comes later -- the last writer of a slot wins as in the reference's loop, by a plain ds_write_b32.  (The
+                            // speculative route's check wants to know WHEN an entry was written: there the stamped ds_max_u64 stays.)
+                            if constexpr (SPEC || SQOA_QDEC_TABW == 0)
+                                __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            else
+                                __hip_atomic_store(reinterpret_cast<uint32_t*>(&s_tab[hv]), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             rec[gb + lane].x = val;
                         }
                         vlast = val;

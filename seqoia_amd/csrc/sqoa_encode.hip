@@ -434,7 +434,7 @@ SQOA_DEV void swar_classify(const uint32_t (&cur)[ENC_S], uint32_t pb, SwarGroup
 template <bool QOI>
 SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S / 4], const unsigned long long (&E)[ENC_S], uint32_t c_in,
                             uint32_t pa, bool has_after, bool eof, lptr8 stage, int lane, unsigned long long le_mask, uint32_t* tabw,
-                            unsigned long long* smask) {
+                            unsigned long long* smask, [[maybe_unused]] uint32_t* pstamp, [[maybe_unused]] uint32_t& qrow64) {
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
     const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)stage);
     const uint32_t sink_addr = stage_addr + 4u * lane;  // a pixel that emits nothing ORs its zeros into a dword of the lane's own, anywhere in the buffer
@@ -455,6 +455,16 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                 const bool ne = (G.b0 >> (8 * i)) & 1u;
                 const uint32_t h = qoi_hash(px);
                 uint32_t cand = tabw[h];  // slot as the previous rows left it
+#if SQOA_ENC_Q_RTN
+                // (one ds_max_rtn_u32 of a stamp that grows with row and lane: what the lanes BELOW me on my slot left -- the L8 path's comment)
+                const uint32_t prev = ne ? __hip_atomic_fetch_max(&pstamp[h], qrow64 + (uint32_t)lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+                const bool lower = prev > qrow64;
+                const int from = lower ? (int)(prev - qrow64 - 1u) : lane;
+                const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
+                if (lower) cand = near;
+                if (ne) tabw[h] = px;                                          // (of the lanes on one slot the highest stays)
+                qrow64 += 64u;
+#else
                 if (ne) __hip_atomic_fetch_or(&smask[h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const unsigned long long m = __hip_atomic_load(&smask[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const unsigned long long lower = m & (le_mask >> 1);  // earlier lanes of this row on my slot
@@ -462,6 +472,7 @@ SQOA_DEV uint32_t swar_emit(const uint32_t (&cur)[ENC_S], SwarGroup (&grp)[ENC_S
                 const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
                 if (lower) cand = near;
                 if (ne && (m & ~le_mask) == 0ull) { tabw[h] = px; smask[h] = 0; }  // last writer of the slot in this row
+#endif
                 const bool hit = ne && cand == px;
                 hitv[i] = hit ? 0x100u | h : 0u;
                 if (hit) Nn = (Nn & ~(0xffu << (8 * i))) | 1u << (8 * i);  // QOI_OP_INDEX: one byte
@@ -588,7 +599,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     __shared__ unsigned long long s_last[QLW][QL8 ? 64 : 1];
     __shared__ unsigned long long s_smask[QW][64];
     // L8 hot loop (SQOA_ENC_Q_RTN): per slot, the stamp (row number * 64 + lane + 1, growing for the wave's lifetime) of the last pixel that took it
-    __shared__ uint32_t s_pstamp[QL8 && SQOA_ENC_Q_RTN ? W : 1][QL8 && SQOA_ENC_Q_RTN ? 64 : 1];
+    __shared__ uint32_t s_pstamp[QOI && SQOA_ENC_Q_RTN ? W : 1][QOI && SQOA_ENC_Q_RTN ? 64 : 1];
     // ... and (SQOA_ENC_Q_RTN == 2) its pixel: with the stamps the sub-tile's "last writer per slot" for the table hop, by plain writes
     __shared__ uint32_t s_lastpx[QL8 && SQOA_ENC_Q_RTN == 2 ? W : 1][QL8 && SQOA_ENC_Q_RTN == 2 ? 64 : 1];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     const lptr8 stage = (lptr8)s_stage[w];
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QLW][lane] = 0; }
-    if (QL8 && SQOA_ENC_Q_RTN) s_pstamp[w % QW][lane] = 0;
+    if (QOI && SQOA_ENC_Q_RTN) s_pstamp[w % QW][lane] = 0;
     [[maybe_unused]] uint32_t qrow64 = 0;   // (SQOA_ENC_Q_RTN: 64 x the rows this wave has probed)
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *(lptr_x4)(stage + i) = u32x4{0u, 0u, 0u, 0u};
     {
@@ -876,6 +887,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         // ---- QOI: colour index entering this sub-tile, and the one leaving it ---------
         uint32_t* tabw = s_tabw[w % QW];
         unsigned long long* smask = s_smask[w % QW];
+        [[maybe_unused]] uint32_t* pstamp = s_pstamp[w % (QOI && SQOA_ENC_Q_RTN ? W : 1)];
         if constexpr (QOI) {
             uint32_t* stamp = s_stamp[w % QW];
             uint32_t* pub = s_tabpub[(j / W) & 1][w % QW];
@@ -940,7 +952,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             }
             sbase = nbytes;
         } else if (swar) {
-            sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, eof, stage, lane, le_mask, tabw, smask);
+            sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, eof, stage, lane, le_mask, tabw, smask, pstamp, qrow64);
         } else {
         uint32_t crun = c_in;  // equal pixels immediately before lane 0 of the step
         uint32_t carry = pb;
@@ -959,6 +971,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const bool ne = !iseq && idx < N;
                 const uint32_t h = qoi_hash(px);
                 uint32_t cand = tabw[h];  // slot as the previous steps left it
+#if SQOA_ENC_Q_RTN
+                const uint32_t prev = ne ? __hip_atomic_fetch_max(&pstamp[h], qrow64 + (uint32_t)lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+                const bool lower = prev > qrow64;
+                const int from = lower ? (int)(prev - qrow64 - 1u) : lane;
+                const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
+                if (lower) cand = near;
+                if (ne) tabw[h] = px;
+                qrow64 += 64u;
+#else
                 if (ne) __hip_atomic_fetch_or(&smask[h], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const unsigned long long m = __hip_atomic_load(&smask[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const unsigned long long lower = m & (le_mask >> 1);  // earlier lanes of this step on my slot
@@ -966,6 +987,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)px);
                 if (lower) cand = near;
                 if (ne && (m & ~le_mask) == 0ull) { tabw[h] = px; smask[h] = 0; }  // last writer of the slot in this step
+#endif
                 if (ne && cand == px) { lo = h; hi = 0; n = 1; }
             }
             if (iseq || idx >= N) { lo = 0; hi = 0; n = 0; }
