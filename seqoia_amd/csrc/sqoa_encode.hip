@@ -342,9 +342,10 @@ SQOA_DEV SwarGroup qoi_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uin
     return o;
 }
 
-#ifndef SQOA_ENC_Q_RTN   // QOI-compat L8 probes: the nearest lower lane on my slot from one ds_max_rtn_u32 (LDS applies an instruction's lanes in ascending order)
-#define SQOA_ENC_Q_RTN 2
+#ifndef SQOA_ENC_Q_RTN   // QOI-compat probes: 2 = the nearest lower lane on my slot from one ds_max_rtn_u32, last writers by plain writes (the LDS
+#define SQOA_ENC_Q_RTN 2  // applies an instruction's lanes in ascending order: tools/ubench/lds_atomic_order.hip); 0 = per-slot 64-bit lane masks, ds_max_u64
 #endif
+static_assert(SQOA_ENC_Q_RTN == 0 || SQOA_ENC_Q_RTN == 2, "SQOA_ENC_Q_RTN");
 #ifndef SQOA_ENC_Q_PIPE
 #define SQOA_ENC_Q_PIPE 1
 #endif
@@ -1269,41 +1270,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     for (int r = 0; r < ENC_S; ++r)
                         if ((nebits >> r) & 1u) atomicMax(&last[qoi_hash(rowpx[r])], (unsigned long long)(r * 64 + lane + 1) << 32 | rowpx[r]);
                 });
-#if SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN
-                // The eight rows' probes with ONE atomic per row for "who of my row is on my slot" (round 5).  gfx950's LDS applies the lanes of
-                // one atomic instruction that meet on an address in ascending lane order, and of one plain write the highest lane's value stays
-                // (tools/ubench/lds_atomic_order.hip: 8 x 10^8 atomics over random, strided and single-address patterns with eight waves on the
-                // LDS, not one out of order; tests/test_gpu_tools.py runs it).  So `ds_max_rtn_u32` of a stamp that grows with row and lane hands
-                // every lane the stamp of the nearest LOWER lane of its row on its slot (or an older row's stamp: none) -- which the per-slot
-                // 64-bit lane masks took a ds_or_b64, a ds_read_b64, a clear by the last writer and a dozen instructions of 64-bit mask
-                // arithmetic to find -- and the row's table update is one ds_write_b32 by every lane that starts an op: the last one wins.
-                // Pipelined as before: row r's ds_bpermute travels with row r + 1's reads.
-                {
-                    uint32_t ph[ENC_S], pcand[ENC_S], pprev[ENC_S];
-                    auto probe_a = [&](int r) {   // my slot's entry as the rows before left it; my stamp into the slot, the stamp before mine out
-                        const uint32_t h = qoi_hash(rowpx[r]);
-                        ph[r] = h;
-                        pcand[r] = s_tabw[w][h];
-                        pprev[r] = 0;
-                        if ((nebits >> r) & 1u)
-                            pprev[r] = __hip_atomic_fetch_max(&s_pstamp[w][h], qrow64 + (uint32_t)(r * 64 + lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    };
-                    probe_a(0);
-#pragma unroll
-                    for (int r = 0; r < ENC_S; ++r) {
-                        const bool ne = (nebits >> r) & 1u;
-                        const uint32_t rb = qrow64 + (uint32_t)(r * 64);
-                        const bool lower = pprev[r] > rb;                                  // a lower lane of THIS row took my slot
-                        const int from = lower ? (int)(pprev[r] - rb - 1u) : lane;
-                        const uint32_t near = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)rowpx[r]);
-                        if (ne) s_tabw[w][ph[r]] = rowpx[r];                                // (of the lanes on one slot the highest stays: the row's last writer)
-                        if (r + 1 < ENC_S) probe_a(r + 1);
-                        const uint32_t cand = lower ? near : pcand[r];
-                        hit[r * 64 + lane] = (uint8_t)((ne && cand == rowpx[r]) ? 0x80u | ph[r] : 0u);
-                    }
-                    qrow64 += (uint32_t)(ENC_S * 64);
-                }
-#elif SQOA_ENC_Q_PIPE
+#if SQOA_ENC_Q_PIPE
                 // The eight rows' probes, software-pipelined by hand.  Row r + 1 can only look at the table after row r has written it, but
                 // LDS executes a wave's instructions in order: nothing has to be WAITED for between row r's writes and row r + 1's reads.
                 // What a row does wait for is its own lane-mask word (who else of the row is on my slot); the write of the table entry
