@@ -343,9 +343,9 @@ SQOA_DEV SwarGroup qoi_group(uint32_t R, uint32_t G, uint32_t B, uint32_t A, uin
 }
 
 #ifndef SQOA_ENC_Q_RTN   // QOI-compat probes: 2 = the nearest lower lane on my slot from one ds_max_rtn_u32, last writers by plain writes (the LDS
-#define SQOA_ENC_Q_RTN 2  // applies an instruction's lanes in ascending order: tools/ubench/lds_atomic_order.hip); 0 = per-slot 64-bit lane masks, ds_max_u64
+#define SQOA_ENC_Q_RTN 3  // applies an instruction's lanes in ascending order: tools/ubench/lds_atomic_order.hip); 0 = per-slot 64-bit lane masks, ds_max_u64
 #endif
-static_assert(SQOA_ENC_Q_RTN == 0 || SQOA_ENC_Q_RTN == 2, "SQOA_ENC_Q_RTN");
+static_assert(SQOA_ENC_Q_RTN == 0 || SQOA_ENC_Q_RTN == 2 || SQOA_ENC_Q_RTN == 3, "SQOA_ENC_Q_RTN");
 #ifndef SQOA_ENC_Q_PIPE
 #define SQOA_ENC_Q_PIPE 1
 #endif
@@ -596,13 +596,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     __shared__ uint32_t s_stamp[QW][64];
     // L8 hot loop without SQOA_ENC_Q_RTN == 2: per slot, (position + 1) << 32 | pixel of the sub-tile's last writer (with it: one row of zeros that
     // the table hop of the row-layout path reads and writes back)
-    constexpr int QLW = QL8 ? (SQOA_ENC_Q_RTN == 2 ? 1 : W) : 1;
+    constexpr int QLW = QL8 ? (SQOA_ENC_Q_RTN >= 2 ? 1 : W) : 1;
     __shared__ unsigned long long s_last[QLW][QL8 ? 64 : 1];
     __shared__ unsigned long long s_smask[QW][64];
     // L8 hot loop (SQOA_ENC_Q_RTN): per slot, the stamp (row number * 64 + lane + 1, growing for the wave's lifetime) of the last pixel that took it
     __shared__ uint32_t s_pstamp[QOI && SQOA_ENC_Q_RTN ? W : 1][QOI && SQOA_ENC_Q_RTN ? 64 : 1];
     // ... and (SQOA_ENC_Q_RTN == 2) its pixel: with the stamps the sub-tile's "last writer per slot" for the table hop, by plain writes
     __shared__ uint32_t s_lastpx[QL8 && SQOA_ENC_Q_RTN == 2 ? W : 1][QL8 && SQOA_ENC_Q_RTN == 2 ? 64 : 1];
+    // L8 hot loop (SQOA_ENC_Q_RTN == 3): per slot, stamp << 32 | pixel of the last pixel that took it
+    __shared__ unsigned long long s_pst64[QL8 && SQOA_ENC_Q_RTN == 3 ? W : 1][QL8 && SQOA_ENC_Q_RTN == 3 ? 64 : 1];
     __shared__ uint32_t s_tabpub[QOI ? 2 : 1][QW][64];
     __shared__ uint32_t s_tabtag[2][W];
     // L8 path: run bytes of the 8 consecutive pixels a lane owns, by their 8 "repeats its predecessor" flags: byte j =
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QLW][lane] = 0; }
     if (QOI && SQOA_ENC_Q_RTN) s_pstamp[w % QW][lane] = 0;
+    if (QL8 && SQOA_ENC_Q_RTN == 3) s_pst64[w % QW][lane] = 0;
     [[maybe_unused]] uint32_t qrow64 = 0;   // (SQOA_ENC_Q_RTN: 64 x the rows this wave has probed)
     for (uint32_t i = lane * 16u; i < (uint32_t)ENC_STG; i += 1024u) *(lptr_x4)(stage + i) = u32x4{0u, 0u, 0u, 0u};
     {
@@ -796,7 +799,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_QTAB_SLEEP);
             }
             const uint32_t tin = s_tabpub[pp][pw % QW][lane];
-            if (QL8 && SQOA_ENC_Q_RTN == 2 && l8) {
+            if (QL8 && SQOA_ENC_Q_RTN == 3 && l8) {
+                // (the slots this sub-tile wrote: the ones whose stamp is of this sub-tile; stamp and pixel are one 8-byte entry)
+                const unsigned long long e = s_pst64[w % QW][lane];
+                pub[lane] = (uint32_t)(e >> 32) > qrow64 ? (uint32_t)e : tin;
+                s_tabw[w % QW][lane] = tin;
+            } else if (QL8 && SQOA_ENC_Q_RTN == 2 && l8) {
                 // (the slots this sub-tile wrote are the ones whose stamp is of this sub-tile; their pixel: the last plain write's)
                 pub[lane] = s_pstamp[w % QW][lane] > qrow64 ? s_lastpx[w % QW][lane] : tin;
                 s_tabw[w % QW][lane] = tin;
@@ -1215,7 +1223,42 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                     }
                 }
                 uint8_t* hit = s_hit[w];
-#if SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN == 2
+#if SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN == 3
+                // gfx950's LDS applies the lanes of ONE instruction that meet on an address in ascending lane order, and a wave's instructions
+                // in program order: an atomic with return hands every lane what was there just before ITS turn (tools/ubench/
+                // lds_atomic_order.hip, run on the box by tests/test_gpu_tools.py).  So ONE `ds_max_rtn_u64` per row of (stamp << 32 | pixel)
+                // -- the stamp grows with row and lane -- returns, to every pixel that starts an op, the most recent EARLIER writer of its
+                // index slot inside this sub-tile, lower lane of its row or earlier row alike, stamp and pixel: the candidate the probe is
+                // after, unless the stamp is older than the sub-tile -- then it is the entry of the table the sub-tile before published,
+                // read where that wave left it (it cannot publish into the same buffer again before this wave has handed its byte position
+                // on: the position chain).  No working copy of the table, no per-slot lane masks, no ds_bpermute, nothing to clear; "the
+                // sub-tile's last writer of every slot", which the table hop publishes before the incoming table is known, is what the
+                // entries hold when the eight atomics are through -- they do not depend on the table and are issued in front of the wait.
+                uint32_t ph[ENC_S];
+                unsigned long long pprev[ENC_S];
+                qoi_table_hop(j, true, [&](unsigned long long*) {
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const uint32_t h = qoi_hash(rowpx[r]);
+                        ph[r] = h;
+                        pprev[r] = 0;
+                        if ((nebits >> r) & 1u)
+                            pprev[r] = __hip_atomic_fetch_max(&s_pst64[w][h], (unsigned long long)(qrow64 + (uint32_t)(r * 64 + lane + 1)) << 32 | rowpx[r],
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                });
+                {
+                    const uint32_t* tinp = s_tabpub[((j - 1) / W) & 1][(j - 1) % W];
+#pragma unroll
+                    for (int r = 0; r < ENC_S; ++r) {
+                        const bool ne = (nebits >> r) & 1u;
+                        const uint32_t tinv = tinp[ph[r]];
+                        const uint32_t cand = (uint32_t)(pprev[r] >> 32) > qrow64 ? (uint32_t)pprev[r] : tinv;
+                        hit[r * 64 + lane] = (uint8_t)((ne && cand == rowpx[r]) ? 0x80u | ph[r] : 0u);
+                    }
+                    qrow64 += (uint32_t)(ENC_S * 64);
+                }
+#elif SQOA_ENC_Q_PIPE && SQOA_ENC_Q_RTN == 2
                 // gfx950's LDS applies the lanes of ONE instruction that meet on an address in ascending lane order: of an atomic with return
                 // every lane gets what the lanes below it left, of a plain write the highest lane's value stays (tools/ubench/lds_atomic_order.hip:
                 // 8 x 10^8 of each over random, strided, clustered and single-address patterns with eight waves on the LDS, none out of order;

@@ -8,8 +8,9 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+template <class T>
 __global__ __launch_bounds__(512) void k(const uint8_t* slots, uint32_t* bad, int rounds, int nslots_pow) {
-  __shared__ uint32_t cell[8][64];
+  __shared__ T cell[8][64];
   __shared__ uint32_t wcell[8][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t nbad = 0, nbadw = 0;
@@ -20,10 +21,12 @@ __global__ __launch_bounds__(512) void k(const uint8_t* slots, uint32_t* bad, in
     const uint32_t base = (uint32_t)r * 64u;
     const bool act = (slots[((size_t)blockIdx.x * rounds + r) * 512 + (threadIdx.x ^ 1)] & 0x80) == 0 || nslots_pow == 0;   // (some lanes sit out)
     uint32_t prev = 0;
-    if (act) prev = __hip_atomic_fetch_max(&cell[w][h], base + lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    // (T = 64 bits: the stamp in the high half, a payload in the low half, as the encoder's stamp << 32 | pixel)
+    if (act) prev = (uint32_t)(__hip_atomic_fetch_max(&cell[w][h], sizeof(T) == 8 ? (T)((unsigned long long)(base + lane + 1u) << 32 | (lane * 2654435761u)) : (T)(base + lane + 1u),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> (sizeof(T) == 8 ? 32 : 0));
     if (act) wcell[w][h] = base + lane + 1u;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t fin = wcell[w][h], finc = cell[w][h];
+    const uint32_t fin = wcell[w][h], finc = (uint32_t)(cell[w][h] >> (sizeof(T) == 8 ? 32 : 0));
     // expected: the highest lower active lane with my slot
     uint32_t want = 0, last = 0;
     for (int j = 0; j < 64; ++j) {
@@ -55,9 +58,13 @@ int main() {
     }
     for (int pw : {6, 3, 1, 0}) {
       (void)hipMemcpy(d, h, n, hipMemcpyHostToDevice); (void)hipMemset(bad, 0, 8);
-      hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 0, 0, d, bad, rounds, pw);
+      hipLaunchKernelGGL(k<uint32_t>, dim3(blocks), dim3(512), 0, 0, d, bad, rounds, pw);
       uint32_t b[2]; (void)hipMemcpy(b, bad, 8, hipMemcpyDeviceToHost);
-      printf("pattern %d, %2d slots: %zu atomics, ds_max_rtn out of order %u, plain-write winner not the highest lane %u\n", pat, 1 << pw, n, b[0], b[1]);
+      (void)hipMemset(bad, 0, 8);
+      hipLaunchKernelGGL(k<unsigned long long>, dim3(blocks), dim3(512), 0, 0, d, bad, rounds, pw);
+      uint32_t b64[2]; (void)hipMemcpy(b64, bad, 8, hipMemcpyDeviceToHost);
+      b[0] += b64[0]; b[1] += b64[1];
+      printf("pattern %d, %2d slots: %zu atomics of 32 and as many of 64 bits, ds_max_rtn out of order %u, plain-write winner not the highest lane %u\n", pat, 1 << pw, n, b[0], b[1]);
     }
   }
   return 0;
