@@ -11,8 +11,9 @@ BUILD := build
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
 CFLAGS_HOST := -std=gnu99 -O2 -fPIC -Wall -Wextra
 
-KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_decode_wave.hip $(CSRC)/sqoa_decode_bal.hip $(CSRC)/sqoa_decode_qoi.hip $(CSRC)/sqoa_strips.hip $(CSRC)/sqoa_runtime.hip
-OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNELS)) $(BUILD)/sqoa_host.o
+KERNELS := $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_decode.hip $(CSRC)/sqoa_decode_wave.hip $(CSRC)/sqoa_decode_bal.hip $(CSRC)/sqoa_decode_qoi.hip $(CSRC)/sqoa_strips.hip $(CSRC)/sqoa_runtime.hip $(CSRC)/sqoa_selftest.hip
+# sqoa_encode_fb.o: sqoa_encode.hip once more, its QOI-compat kernels in the form that does not rest on the LDS's lane order (sqoa_selftest.hip)
+OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNELS)) $(BUILD)/sqoa_encode_fb.o $(BUILD)/sqoa_host.o
 
 all: lib oracle tools
 
@@ -21,6 +22,10 @@ lib: $(OUT)/libsqoa_mi355x.so
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/sqoa_common.h $(CSRC)/sqoa_decode_parts.h include/sqoa_hip.h include/seqoia.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/sqoa_encode_fb.o: $(CSRC)/sqoa_encode.hip $(CSRC)/sqoa_common.h include/sqoa_hip.h include/seqoia.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DSQOA_LDS_ORDER_FB -c $< -o $@
 
 $(BUILD)/sqoa_host.o: $(CSRC)/sqoa_host.c include/sqoa_hip.h include/seqoia.h
 	@mkdir -p $(BUILD)
@@ -42,7 +47,7 @@ tools/bin/%: tools/%.c include/seqoia.h include/sqoa_hip.h
 # the hardware property the QOI-compat encoder's probes rest on (sqoa_encode.hip, SQOA_ENC_Q_RTN): checked on the GPU box by tests/test_gpu_tools.py
 tools/bin/lds_atomic_order: tools/ubench/lds_atomic_order.hip
 	@mkdir -p tools/bin
-	$(HIPCC) --offload-arch=gfx950 -O2 $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O2 $< -o $@
 
 clean:
 	rm -rf $(BUILD) $(OUT)/*.so tools/bin

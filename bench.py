@@ -286,6 +286,9 @@ class Uniform:
         self.enc.launch(stream)
         self.dec.launch(stream)
 
+    def decoded_ok(self, torch):
+        return bool(torch.equal(self.dec.out, self.px))
+
     def close(self):
         self.dec.close()
         self.enc.close()
@@ -322,8 +325,12 @@ class Suite:
         self.dec.launch()
         dres = self.dec.results()
         assert (dres["status"] == 0).all(), "decode failed"
+        self._offs, self._sizes = offs, sizes
         for i, (o, s) in enumerate(zip(offs, sizes)):  # round trip of every image (sqoabench.c:448-455)
             assert torch.equal(self.dec.image(i), self.px[o : o + s]), f"round trip mismatch, image {self.idx[i]}"
+
+    def decoded_ok(self, torch):
+        return all(bool(torch.equal(self.dec.image(i), self.px[o : o + s])) for i, (o, s) in enumerate(zip(self._offs, self._sizes)))
 
     def step(self, stream):
         self.enc.launch(stream)
@@ -397,7 +404,14 @@ def secondary(sq, torch, dev, headline, k=5):
         warm(wl.enc)
         e = wl.enc.time(k) / k      # (each kernel behind its OWN warm-up, like the headline's plan_launch_ms: behind the other kernel's it is
         warm(wl.dec)                #  that kernel's clocks and temperature that are measured -- the QOI-compat encode 2.71 against 2.47 ms)
+        # (what the timed launches leave is looked at BEFORE results() is asked: a launch that decoded nothing -- round 5's lazy skip did that to
+        # the speculative QOI-compat route, and results() repaired it out of sight -- must not yield a time)
+        wl.dec.out.zero_()
+        torch.cuda.synchronize()
         d = wl.dec.time(k) / k
+        torch.cuda.synchronize()
+        assert wl.decoded_ok(torch), f"{name}: the timed decode launches did not reproduce the pixels"
+        assert (wl.dec.results()["status"] == 0).all(), name
         out[name] = {
             "encode_ms": round(e, 4), "decode_ms": round(d, 4),
             "encode_mpps": round(wl.pixels / e / 1e3, 1), "decode_mpps": round(wl.pixels / d / 1e3, 1),
@@ -413,7 +427,11 @@ def secondary(sq, torch, dev, headline, k=5):
             d4.launch()
             assert (d4.results()["status"] == 0).all() and torch.equal(d4.out[..., :cc], wl.px) and bool((d4.out[..., 3] == 255).all()), "4-channel decode mismatch"
             warm(d4)
+            d4.out.zero_()
+            torch.cuda.synchronize()
             t4 = d4.time(k) / k
+            torch.cuda.synchronize()
+            assert torch.equal(d4.out[..., :cc], wl.px) and (d4.results()["status"] == 0).all(), f"{name}: the timed 4-channel decode launches did not reproduce the pixels"
             out[name].update({"decode_to_4_channels_ms": round(t4, 4), "decode_to_4_channels_mpps": round(wl.pixels / t4 / 1e3, 1),
                               "decode_to_4_channels_roofline_frac": round((wl.enc_bytes + wl.pixels * 4) / t4 / 1e6 / HBM_PEAK_GBS, 4)})
             d4.close()
@@ -432,6 +450,10 @@ def secondary(sq, torch, dev, headline, k=5):
     wl.dec.launch()
     assert (wl.dec.results()["status"] == 0).all() and torch.equal(wl.dec.out, h.px), "QOI-compat round trip mismatch"
     row(f"qoi_compat=1, {n} x {ww}x{hh} RGBA (the headline batch)", wl)
+    # class photo (LUMA ops throughout: the content the balanced decoder's table look-ups like least), as RGBA and -- what a
+    # photograph usually is -- as RGB decoded to its own three channels and, as sqoabench's timed decode asks (sqoabench.c:490-494), to four
+    row(f"class photo {n} x {ww}x{hh} RGBA, qoi_compat=0", Uniform(sq, torch, dev, n, ww, hh, 4, "photo", 0))
+    row(f"class photo {n} x {ww}x{hh} RGB, qoi_compat=0", Uniform(sq, torch, dev, n, ww, hh, 3, "photo", 0), four=True)
     for size in (512, 64):
         for qoi in (0, 1):
             row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi), four=True)
@@ -715,6 +737,9 @@ def run_rank(args):
             "board_power_card": power[3] if power else None,
             "encode_mpps_rank0": round(wl.pixels / enc_ms / 1e3, 1),
             "decode_mpps_rank0": round(wl.pixels / dec_ms / 1e3, 1),
+            # which form of the QOI-compat kernels this device gets (1: the ones that rest on the LDS's lane order -- the device passed the library's
+            # probe of it, sqoa_selftest.hip; 0: the order-free ones)
+            "lds_lane_order_probe_passed": int(sq.load().sqoa_hip_lds_order(local)),
             "roofline_frac_of_n_gpus": round(total_px * args.steps / dt / (world * HBM_PEAK_GBS * 1e9 / 4), 4),
         },
     }
@@ -723,7 +748,7 @@ def run_rank(args):
     enc_pmc = {} if c5 else counters_from_profile("encode", wl.n, s)
     dec_pmc = {} if c5 else counters_from_profile("decode", wl.n, s)
     src = enc_pmc.get("source") or dec_pmc.get("source")
-    dominant = "decode" if dec_ms >= enc_ms else "encode"
+    dominant = "decode" if dec_step_ms >= enc_step_ms else "encode"
 
     def pmc_fields(row, pmc):
         # from the committed PMC summary of this very source (None / absent otherwise): HBM bytes per launch, instructions retired
@@ -742,11 +767,27 @@ def run_rank(args):
 
     # `plan_launch_ms`: HIP events around whole plan launches (the kernel named here plus the plan's stand-by launches behind it:
     # two for a decode plan, ~10 us in all), k launches back to back on the plan's stream, in a loop of its own behind the timed region
+    # `frac` / `achieved`: from the launch INSIDE the encode -> decode step (`in_step_ms`: what `value` is made of -- a kernel behind the other one
+    # shares the board's power budget with it and is not the kernel in a loop of its own); `frac_alone` / `achieved_alone`: from `plan_launch_ms`.
+    # `cycles_per_64px_per_cu`: in-step time x shader clock (hwmon, read under the step) x compute units / (pixels / 64) -- the figure that
+    # survives a change of box: the boxes of the pool differ by 5 % in the clock they hold under the 1 400 W cap.
+    try:
+        n_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    except Exception:  # noqa: BLE001
+        n_cus = 256
+    sclk = power[2] if power else None
+
+    def cyc(ms):
+        return round(ms * 1e-3 * sclk * 1e6 * n_cus / (wl.pixels / 64.0), 1) if sclk else None
+
     roof_enc = pmc_fields({
         "kernel": enc_pmc.get("kernel", "sqoa::encode_kernel<8, false>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-        "achieved": round(wl.read_bytes / enc_ms / 1e6, 1),  # algorithmic READ bytes (channels B/px) / plan launch time
-        "frac": round(wl.read_bytes / enc_ms / 1e6 / HBM_PEAK_GBS, 4),
-        "achieved_read_plus_write": round((wl.read_bytes + wl.enc_bytes) / enc_ms / 1e6, 1),
+        "achieved": round(wl.read_bytes / enc_step_ms / 1e6, 1),  # algorithmic READ bytes (channels B/px) / the launch's time in the step
+        "frac": round(wl.read_bytes / enc_step_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "achieved_alone": round(wl.read_bytes / enc_ms / 1e6, 1),
+        "frac_alone": round(wl.read_bytes / enc_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "cycles_per_64px_per_cu": cyc(enc_step_ms), "compute_units": n_cus,
+        "achieved_read_plus_write": round((wl.read_bytes + wl.enc_bytes) / enc_step_ms / 1e6, 1),
         # the encoder also writes enc_bytes / read_bytes bytes per byte read: at the measured copy rate of the chip (6.29 TB/s of read +
         # write traffic) the READ rate cannot exceed this fraction of the 8 TB/s peak on this content
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS / (1.0 + wl.enc_bytes / wl.read_bytes), 4),
@@ -755,15 +796,18 @@ def run_rank(args):
     }, enc_pmc)
     roof_dec = pmc_fields({
         "kernel": dec_pmc.get("kernel", "sqoa::bal::decode_bal_kernel<8, 16, false>"), "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-        "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),  # stream bytes read + pixel bytes written
-        "frac": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "achieved": round((wl.enc_bytes + wl.write_bytes) / dec_step_ms / 1e6, 1),  # stream bytes read + pixel bytes written / the launch's time in the step
+        "frac": round((wl.enc_bytes + wl.write_bytes) / dec_step_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "achieved_alone": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6, 1),
+        "frac_alone": round((wl.enc_bytes + wl.write_bytes) / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
+        "cycles_per_64px_per_cu": cyc(dec_step_ms), "compute_units": n_cus,
         "practical_ceiling_frac": round(HBM_COPY_GBS / HBM_PEAK_GBS, 4),   # all of its bytes are streaming traffic
         "plan_launch_ms": round(dec_ms, 4),
         "in_step_ms": round(dec_step_ms, 4),
     }, dec_pmc)
     out["roofline"] = dict(roof_dec if dominant == "decode" else roof_enc)
     out["roofline"]["dominant_by_time"] = dominant
-    out["roofline"]["share_of_step"] = round(max(enc_ms, dec_ms) / (enc_ms + dec_ms), 3)
+    out["roofline"]["share_of_step"] = round(max(enc_step_ms, dec_step_ms) / (enc_step_ms + dec_step_ms), 3)
     if src:
         out["roofline"]["traffic_source"] = src
     out["roofline"]["encode"] = roof_enc

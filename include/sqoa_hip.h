@@ -87,6 +87,18 @@ const char *sqoa_hip_last_error(void);
  * pointers are process-wide and not synchronised against calls in flight).  NULL = back to malloc / free, the default. */
 void sqoa_hip_set_allocator(void *(*malloc_fn)(size_t), void (*free_fn)(void *));
 
+/* The default QOI-compat kernels rest on a property of the LDS that the ISA manual does not state -- that the lanes of ONE instruction which
+ * meet on an address are applied in ascending lane order (the encoder's index probe, seqoia.h:563-572, is one atomic with return per row;
+ * the decoder's index update, seqoia.h:785-787, a plain write).  The library carries order-free forms of those kernels as well and ASKS the
+ * device, once per device and process, when the first plan is created on it (a probe of a few hundred microseconds): only a device that
+ * passes gets the fast forms.  SQOA_HIP_LDS_ORDER=0 in the environment (read whenever a plan is created or updated) forces the order-free
+ * forms, =1 trusts the order without asking.  Output is byte-identical either way on a device that passes.
+ * sqoa_hip_lds_order: 1 = launches on `device` take the forms that rest on the order, 0 = the order-free ones, -1 = no such device.
+ * sqoa_hip_lds_order_probe: the probe's raw counts on `device` -- out[0] atomic returns out of order, out[1] plain-write winners that are not
+ * the highest lane, out[2] lanes checked; returns 0 when it ran. */
+int sqoa_hip_lds_order(int device);
+int sqoa_hip_lds_order_probe(int device, unsigned int out[3]);
+
 /* Worst-case stream size for one image: w*h*(ch+1)+14+8 (reference
  * seqoia.h:487-489) plus the start byte the reference forgets (seqoia.h:513),
  * rounded up to 256 so consecutive slots stay aligned. 0 if desc is invalid. */

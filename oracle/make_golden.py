@@ -152,11 +152,69 @@ def headline_digests(ref, n=1024, w=1024, h=1024, ch=4, seed=1):
     return dict(cls="mixed", w=w, h=h, channels=ch, seed=seed, count=n, columns=["sqoa_len", "sqoa_fnv", "qoi_len", "qoi_fnv"], rows=rows)
 
 
+def _pool_map(fn, items):
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(len(os.sched_getaffinity(0))) as ex:   # (the ctypes calls release the GIL)
+        return list(ex.map(fn, items))
+
+
+C4_SIZES = (64, 128, 256, 512)
+
+
+def c4_digests(ref, n=4096, seed=1):
+    """BASELINE.json configs[3] in full: class icon, 3 channels, seed 1, img 0..4095 at 64^2, 128^2, 256^2 and 512^2, BOTH wire formats --
+    length and FNV-1a-64 of every one of the 4 x 4 096 x 2 streams from the compiled reference (seqoia.h:456-650).
+    Arrays [size][format][image]: lens uint32, fnv uint64."""
+    lens = np.zeros((len(C4_SIZES), 2, n), np.uint32)
+    fnv = np.zeros((len(C4_SIZES), 2, n), np.uint64)
+    for si, size in enumerate(C4_SIZES):
+        def one(img, size=size):
+            px = po.synth(size, size, 3, "icon", seed, img)
+            s, q = ref.encode(px, size, size, 3, 0), ref.encode(px, size, size, 3, 1)
+            return len(s), po.fnv1a64(s), len(q), po.fnv1a64(q)
+
+        for img, (ls, fs, lq, fq) in enumerate(_pool_map(one, range(n))):
+            lens[si, 0, img], fnv[si, 0, img], lens[si, 1, img], fnv[si, 1, img] = ls, fs, lq, fq
+        print(f"  C4 {size}x{size}: SQOA {int(lens[si, 0].sum())} B, QOI {int(lens[si, 1].sum())} B", flush=True)
+    return dict(sizes=np.array(C4_SIZES, np.uint32), lens=lens, fnv=fnv, seed=np.uint32(seed), channels=np.uint32(3))
+
+
+def c5_digests(ref, seed=1):
+    """BASELINE.json configs[4] in full: all 65 536 suite-shaped images (seqoia_amd/suite.py: directory -> shape and class, generator index = the
+    image's global number, seed 1), SQOA-native -- length and FNV-1a-64 of every stream from the compiled reference.  About 30 Gpixel: a few
+    core-minutes.  Arrays [image]: lens uint32, fnv uint64."""
+    from seqoia_amd import suite
+
+    imgs = suite.images(suite.C5_IMAGES)
+
+    def one(im):
+        px = po.synth(im.width, im.height, im.channels, im.cls, seed, im.index)
+        s = ref.encode(px, im.width, im.height, im.channels, 0)
+        return len(s), po.fnv1a64(s)
+
+    rows = []
+    for a in range(0, len(imgs), 4096):
+        rows += _pool_map(one, imgs[a : a + 4096])
+        print(f"  C5 {len(rows)} / {len(imgs)}", flush=True)
+    lens = np.array([r[0] for r in rows], np.uint32)
+    fnv = np.array([r[1] for r in rows], np.uint64)
+    return dict(lens=lens, fnv=fnv, seed=np.uint32(seed), count=np.uint32(len(imgs)))
+
+
 def main():
     ref = po.reference()
     if ref is None:
         sys.exit("oracle/_ref/libsqoa_ref.so missing and /root/reference absent: cannot regenerate goldens")
     os.makedirs(OUT, exist_ok=True)
+    if "--c4" in sys.argv or "--c5" in sys.argv:  # the (slow) full-set digest tables of configs[3] / configs[4], as compressed numpy archives
+        if "--c4" in sys.argv:
+            np.savez_compressed(os.path.join(OUT, "c4_digests.npz"), **c4_digests(ref))
+            print("wrote c4_digests.npz")
+        if "--c5" in sys.argv:
+            np.savez_compressed(os.path.join(OUT, "c5_digests.npz"), **c5_digests(ref))
+            print("wrote c5_digests.npz")
+        return
     if "--headline" in sys.argv:  # only the (slow) whole-batch digest table
         json.dump(headline_digests(ref), open(os.path.join(OUT, "headline_digests.json"), "w"), separators=(",", ":"))
         print("wrote headline_digests.json")

@@ -60,6 +60,8 @@ SYMBOLS = {
     "sqoa_read": (C.c_void_p, [C.c_char_p, C.POINTER(Desc), C.c_int]),
     "sqoa_hip_set_allocator": (None, [C.c_void_p, C.c_void_p]),
     "sqoa_hip_device_count": (C.c_int, []),
+    "sqoa_hip_lds_order": (C.c_int, [C.c_int]),
+    "sqoa_hip_lds_order_probe": (C.c_int, [C.c_int, C.POINTER(C.c_uint)]),
     "sqoa_hip_last_error": (C.c_char_p, []),
     "sqoa_hip_encode_bound": (C.c_size_t, [C.POINTER(Desc)]),
     "sqoa_hip_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_ulonglong)]),

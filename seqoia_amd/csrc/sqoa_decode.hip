@@ -558,7 +558,11 @@ extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, con
 // `n_b`, `shape_b`: the last n_b of the streams that get a workgroup each are launched apart from the others, with a shape of their own (the plan
 // splits lists of mixed output formats: sqoa_runtime.hip) -- here, behind the others, or (`b_launched`) by the caller on a side stream, whose
 // `join_event` this stream waits for before the kernels that look at every job's status
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
+// `wave_only`: every job is SQOA_HIP_JOB_WAVEONLY -- neither the speculative QOI-compat pass nor the kernels behind the wave decoder are launched.
+// `skip_standby`: the plan's lazy skip (sqoa_runtime.hip) -- ONLY the kernels behind the wave decoder (retry, QOI-compat, fallback) are left out;
+// the speculative pass of the multi-pass QOI-compat streams and the scans it reads are part of every launch (a stream it accepts never marks its
+// row as "stand-by used", so a plan of such streams would otherwise have lost its decode with the skip).
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, int skip_standby, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int small = shape & 1;
@@ -582,6 +586,6 @@ extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* 
     if (e != hipSuccess) return e;
     if (n_b > 0 && b_launched && join_event) e = hipStreamWaitEvent(stream, (hipEvent_t)join_event, 0);
     if (e != hipSuccess) return e;
-    if (wave_only) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
+    if (wave_only || skip_standby) return hipSuccess;   // every job is SQOA_HIP_JOB_WAVEONLY: what the wave decoder declines goes back to the caller as SLOWPATH
     return sqoa_launch_decode_standby(d_jobs, d_ids, n, small, ((shape | (n_b > 0 ? shape_b : 0)) & 8) ? 1 : 0, d_results, stream);
 }

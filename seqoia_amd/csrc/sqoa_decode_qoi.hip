@@ -134,7 +134,9 @@ static_assert(QK_CHUNK == DP_CHUNK_BYTES, "the speculative pass indexes the pass
 // and at the end of its own chunks; dq_verify_kernel accepts the stream only if EVERY workgroup's guessed start state equals the
 // end state of the workgroup in front -- by induction from the first one, which starts exactly, all pixels are then the
 // reference's -- and leaves it to the one-workgroup decoder (status still SLOWPATH) otherwise.
-template <int W, bool SPEC = false, bool BAL = SQOA_QDEC_BAL != 0>
+// TABW: the resolver's index update as a plain write, which rests on the LDS applying an instruction's lanes in ascending order (the instance for
+// devices that have passed the library's probe of that order, sqoa_selftest.hip); false: the stamped ds_max_u64, which does not.
+template <int W, bool SPEC = false, bool BAL = SQOA_QDEC_BAL != 0, bool TABW = SQOA_QDEC_TABW != 0>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void decode_qoi_kernel(const sqoa_hip_job* __restrict__ jobs,
                                                                                                    const int* __restrict__ job_ids,
                                                                                                    sqoa_hip_result* __restrict__ results,
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                             // an instruction's lanes in ascending order: tools/ubench/lds_atomic_order.hip, run by the GPU tests), and a later
                             // group's write comes later -- the last writer of a slot wins as in the reference's loop, by a plain ds_write_b32.  (The
                             // speculative route's check wants to know WHEN an entry was written: there the stamped ds_max_u64 stays.)
-                            if constexpr (SPEC || SQOA_QDEC_TABW == 0)
+                            if constexpr (SPEC || !TABW)
                                 __hip_atomic_fetch_max(&s_tab[hv], (unsigned long long)((c << 10) + gb + (uint32_t)lane + 1u) << 32 | val, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                             else
@@ -1021,9 +1023,16 @@ extern "C" size_t sqoa_dq_state_bytes(void) { return 2 * sizeof(sqoa::dq_state);
 // `small`: the plan's streams are short (many more images than the chip holds workgroups of the large shape)
 // (The producers' walk balanced over the lanes for every plan: on RUN-heavy streams, whose chunks hold few ops, it is as fast as the walk
 // over a lane's own bytes -- 4096 icons of 512 x 512: 2.17 against 2.18 ms, same call -- and on the headline batch 8.18 -> 7.75 ms.)
+extern "C" int sqoa_lds_order_fb(void);   // sqoa_selftest.hip: the order-free kernels on the current device?
 extern "C" hipError_t sqoa_launch_decode_qoi(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (small) hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W_SMALL>), dim3(n), dim3(SQOA_QDEC_W_SMALL * 64), 0, stream, d_jobs, d_ids, d_results);
-    else hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W>), dim3(n), dim3(SQOA_QDEC_W * 64), 0, stream, d_jobs, d_ids, d_results);
+    constexpr bool B = SQOA_QDEC_BAL != 0;
+    if (sqoa_lds_order_fb()) {   // (a device that has not passed the probe of the LDS's lane order, or SQOA_HIP_LDS_ORDER=0: the stamped ds_max_u64 update)
+        if (small) hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W_SMALL, false, B, false>), dim3(n), dim3(SQOA_QDEC_W_SMALL * 64), 0, stream, d_jobs, d_ids, d_results);
+        else hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W, false, B, false>), dim3(n), dim3(SQOA_QDEC_W * 64), 0, stream, d_jobs, d_ids, d_results);
+    } else {
+        if (small) hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W_SMALL, false, B, SQOA_QDEC_TABW != 0>), dim3(n), dim3(SQOA_QDEC_W_SMALL * 64), 0, stream, d_jobs, d_ids, d_results);
+        else hipLaunchKernelGGL((sqoa::decode_qoi_kernel<SQOA_QDEC_W, false, B, SQOA_QDEC_TABW != 0>), dim3(n), dim3(SQOA_QDEC_W * 64), 0, stream, d_jobs, d_ids, d_results);
+    }
     return hipGetLastError();
 }

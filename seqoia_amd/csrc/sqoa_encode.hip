@@ -20,13 +20,30 @@
 
 #include "sqoa_common.h"
 
+// This file is built TWICE into the one library (Makefile).  The second build, -DSQOA_LDS_ORDER_FB, holds the QOI-compat kernels in the form
+// that does NOT rest on the order in which the LDS applies one instruction's lanes (per-slot 64-bit lane masks and ds_max_u64: SQOA_ENC_Q_RTN = 0,
+// below), as sqoa::fb::encode_kernel behind sqoa_launch_encode_*_fb; the launchers of the first build hand QOI-compat launches over to them on a
+// device that has not passed the library's probe of that order (sqoa_selftest.hip; SQOA_HIP_LDS_ORDER=0 forces it: the GPU tests run the
+// QOI-compat parity set on both forms).
+#ifdef SQOA_LDS_ORDER_FB
+#undef SQOA_ENC_Q_RTN
+#define SQOA_ENC_Q_RTN 0
+#define SQOA_ENC_NS_OPEN namespace sqoa { namespace fb {
+#define SQOA_ENC_NS_CLOSE } }
+#define SQOA_ENC_SYM(name) name##_fb
+#else
+#define SQOA_ENC_NS_OPEN namespace sqoa {
+#define SQOA_ENC_NS_CLOSE }
+#define SQOA_ENC_SYM(name) name
+#endif
+
 #ifndef SQOA_PRIO_T1  // progress (in 64ths of the image) at which a workgroup drops to wave priority 2, 1, 0
 #define SQOA_PRIO_T1 40
 #define SQOA_PRIO_T2 54
 #define SQOA_PRIO_T3 61
 #endif
 
-namespace sqoa {
+SQOA_ENC_NS_OPEN
 
 constexpr int ENC_S = 8;               // steps per sub-tile
 constexpr int ENC_SUB = ENC_S * 64;    // pixels per sub-tile
@@ -1567,6 +1584,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
 // ---- launch -----------------------------------------------------------------------------
 
+#ifndef SQOA_LDS_ORDER_FB
+extern "C" int sqoa_lds_order_fb(void);   // sqoa_selftest.hip: the order-free QOI-compat kernels on the current device?
+extern "C" hipError_t sqoa_launch_encode_tab_fb(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                                sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream);
+extern "C" hipError_t sqoa_launch_encode_small_fb(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                                  sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
                                              sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream);
 // `cus`: compute units of the device the plan lives on (the plan asks the device it was created for, not the calling thread's current one)
@@ -1574,11 +1597,17 @@ extern "C" hipError_t sqoa_launch_encode(const sqoa_hip_job* d_jobs, const int* 
                                          sqoa_hip_result* d_results, int cus, hipStream_t stream) {
     return sqoa_launch_encode_tab(d_jobs, d_ids, n, qoi, d_results, nullptr, cus, stream);
 }
+#endif
 
 // `d_qtab_in` (QOI-compat strip jobs only, else null): the colour index entering job i, 64 dwords at [64 * i]
-extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                             sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream) {
+extern "C" hipError_t SQOA_ENC_SYM(sqoa_launch_encode_tab)(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                                           sqoa_hip_result* d_results, const uint32_t* d_qtab_in, int cus, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+#ifndef SQOA_LDS_ORDER_FB
+    if (qoi && sqoa_lds_order_fb()) return sqoa_launch_encode_tab_fb(d_jobs, d_ids, n, qoi, d_results, d_qtab_in, cus, stream);
+#else
+    if (!qoi) return hipErrorInvalidValue;   // (this build holds the QOI-compat kernels only)
+#endif
     // 8 waves per image, four images per CU: the kernel is VALU-issue bound (tools/ubench/valu_table.hip)
 #ifndef SQOA_ENC_W
 #define SQOA_ENC_W 8
@@ -1598,19 +1627,28 @@ extern "C" hipError_t sqoa_launch_encode_tab(const sqoa_hip_job* d_jobs, const i
         if (!d_qtab_in && n > 2 * cus) hipLaunchKernelGGL((encode_kernel<WM, true>), dim3(n), dim3(WM * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
         else hipLaunchKernelGGL((encode_kernel<W, true>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, d_qtab_in);
     }
+#ifndef SQOA_LDS_ORDER_FB
     else hipLaunchKernelGGL((encode_kernel<W, false>), dim3(n), dim3(W * 64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
+#endif
     return hipGetLastError();
 }
 
 // Many SMALL images (the plan decides: sqoa_runtime.hip): one wave per image.  An image of a few sub-tiles gives eight waves
 // nothing to share but the chain hops and the workgroup's prologue: 16 384 icons of 128 x 128 0.65 -> 0.41 ms, 4096 of
 // 64 x 64 66 -> 45 us; from 256 x 256 on the shapes are equal (tools/time_tiny.py).
-extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
-                                               sqoa_hip_result* d_results, hipStream_t stream) {
+extern "C" hipError_t SQOA_ENC_SYM(sqoa_launch_encode_small)(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int qoi,
+                                                             sqoa_hip_result* d_results, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+#ifndef SQOA_LDS_ORDER_FB
+    if (qoi && sqoa_lds_order_fb()) return sqoa_launch_encode_small_fb(d_jobs, d_ids, n, qoi, d_results, stream);
+#else
+    if (!qoi) return hipErrorInvalidValue;
+#endif
     if (qoi) hipLaunchKernelGGL((encode_kernel<1, true>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
+#ifndef SQOA_LDS_ORDER_FB
     else hipLaunchKernelGGL((encode_kernel<1, false>), dim3(n), dim3(64), 0, stream, d_jobs, d_ids, d_results, (const uint32_t*)nullptr);
+#endif
     return hipGetLastError();
 }
 
-}  // namespace sqoa
+SQOA_ENC_NS_CLOSE

@@ -21,13 +21,14 @@ extern "C" hipError_t sqoa_launch_encode_small(const sqoa_hip_job* d_jobs, const
                                                sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_wave(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_decode_standby(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int small, int retry, sqoa_hip_result* d_results, hipStream_t stream);
-extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, const sqoa_dp_tables* dp,
+extern "C" hipError_t sqoa_launch_decode(const sqoa_hip_job* d_jobs, const int* d_ids, int n, int shape, int n_b, int shape_b, int b_launched, void* join_event, int wave_only, int skip_standby, const sqoa_dp_tables* dp,
                                          sqoa_hip_result* d_results, hipStream_t stream);
 extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa_hip_result* d_results, const sqoa_st_tables* st, hipStream_t stream);
 extern "C" uint32_t sqoa_dp_chunks(uint32_t src_size, int lb);
 extern "C" uint32_t sqoa_dp_per_wg(unsigned long long total_chunks, unsigned wgs, size_t* row_bytes);
 extern "C" size_t sqoa_dq_state_bytes(void);
 extern "C" hipError_t sqoa_launch_dp_classify(const sqoa_hip_job* d_jobs, const int* d_ids, int n, void* d_word, hipStream_t stream);
+extern "C" int sqoa_lds_order_refresh(int device);   // sqoa_selftest.hip
 
 // A stream decoded by one workgroup runs at one compute unit's instruction issue (r = about 1.2 MB of stream per ms) however
 // empty the chip is; the three-pass decode costs SQOA_DP_COST x the instructions but spreads them over every CU (R = about
@@ -377,6 +378,9 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || cus <= 0) cus = 256;
     p->cus = cus;
     p->dp.cus = cus;
+    // Which form of the QOI-compat kernels launches on this device take (the device is asked ONCE per process, here, before anything could be
+    // capturing a stream; SQOA_HIP_LDS_ORDER=0 / 1 is read with every fill like the plan's other knobs): sqoa_selftest.hip
+    (void)sqoa_lds_order_refresh(p->device);
     typedef sqoa::dp_image dp_image_row;   // (sqoa_common.h: the kernels read the very same structs)
     typedef sqoa::dp_wg dp_wg_row;
     std::vector<dp_image_row> dp_images;
@@ -452,12 +456,30 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         const int mode = knob && knob[0] == '1' ? 1 : knob && knob[0] == '0' ? -1 : 0;
         std::vector<int> order(ids_a.size());
         int n_multi = 0;
-        // (streams to four channels at aligned addresses will take the balanced kernel, which is 12 % faster on a full chip and a third
-        // faster with a compute unit to itself than the kernel the model's constants were fitted to: tools/time_few.py, 256 streams of
-        // 1 Mpixel 1.37 ms chained against 1.56 in three passes, 1024 of them 2.59 against 5.96)
-        bool bal_cand = !ids_a.empty() && bytes / ids_a.size() >= (12u << 10) && !p->small;
-        for (int i : ids_a) if (!(jobs[i].desc.channels == 3 || (jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull)))) bal_cand = false;
-        if (const char* kb = getenv("SQOA_HIP_DEC_BAL")) if (kb[0] == '0') bal_cand = false;
+        // (streams that will take the balanced kernel: it is 12 % faster on a full chip and a third faster with a compute unit to itself than the
+        // kernel the model's constants were fitted to: tools/time_few.py, 256 streams of 1 Mpixel 1.37 ms chained against 1.56 in three passes,
+        // 1024 of them 2.59 against 5.96.  The SAME predicate as shape_of below -- over the whole list, the multi-pass prefix is not known yet --,
+        // so that a list the balanced kernel will not take -- to three channels alone, run-heavy, mostly not four-channel bytes -- is not
+        // routed with constants fitted to a kernel it does not run)
+        bool bal_cand = false;
+        {
+            unsigned long long by4 = 0, px = 0;
+            bool shaped = true, all4 = true;
+            for (int i : ids_a) {
+                const sqoa_hip_job& j = jobs[i];
+                px += (unsigned long long)j.desc.width * j.desc.height;
+                if (j.desc.channels == 4) by4 += j.src_size;
+                if (!(j.desc.channels == 3 || (j.desc.channels == 4 && !(j.dst & 3ull)))) all4 = false;
+                if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
+            }
+            const bool roomy = bytes / ids_a.size() >= (12u << 10);
+            int wide = roomy && 4u * by4 >= 3u * bytes, sweep = shaped && roomy && bytes < px;
+            if (const char* kw = getenv("SQOA_HIP_DEC_WIDE")) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
+            if (const char* ks = getenv("SQOA_HIP_DEC_SWEEP")) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
+            int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !p->small;
+            if (const char* kb = getenv("SQOA_HIP_DEC_BAL")) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
+            bal_cand = bal && all4;
+        }
         int rc = decode_route(sizes.data(), (int)sizes.size(), cus, mode, bal_cand ? SQOA_DP_COST_BAL : SQOA_DP_COST, bal_cand ? SQOA_DP_SOLO_BAL : SQOA_DP_SOLO, order.data(), &n_multi);
         if (rc) return rc;
         std::vector<int> sorted(ids_a.size());
@@ -753,9 +775,18 @@ static int plan_enqueue(sqoa_hip_plan* p, hipStream_t s) {
             HIP_TRY(sqoa_launch_decode_wave(p->d_jobs, p->d_ids + p->n_sqoa - p->n_chain_b, p->n_chain_b, p->shape_b, p->d_results, p->side), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipEventRecord(p->ev_join, p->side), SQOA_HIP_ELAUNCH);
         }
-        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, fork ? 1 : 0, fork ? (void*)p->ev_join : nullptr, (p->wave_only || p->lazy_skip) ? 1 : 0, &p->dp,
+        // The lazy skip leaves out the kernels BEHIND the wave decoder and nothing else (the speculative QOI-compat pass keeps running: the streams
+        // it accepts never mark their rows).  Not while the stream is being captured: a graph outlives the plan's skip state -- replayed over
+        // streams that need the stand-by kernels after all it would have no one to run them, and sqoa_hip_plan_results could not know.
+        bool skip = p->lazy_skip && !p->wave_only;
+        if (skip) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+            if (cap != hipStreamCaptureStatusNone) skip = false;
+        }
+        HIP_TRY(sqoa_launch_decode(p->d_jobs, p->d_ids, p->n_sqoa, p->shape, p->n_chain_b, p->shape_b, fork ? 1 : 0, fork ? (void*)p->ev_join : nullptr, p->wave_only ? 1 : 0, skip ? 1 : 0, &p->dp,
                                    p->d_results, s), SQOA_HIP_ELAUNCH);
-        p->skipped_last = p->lazy_skip && !p->wave_only;
+        p->skipped_last = skip;
         p->launched = true;
     }
     return 0;
@@ -791,14 +822,18 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
             slow = slow || out[i].status == SQOA_HIP_ST_SLOWPATH;
             used = used || reinterpret_cast<const unsigned char*>(&out[i].desc)[11] != 0;
         }
-        if (p->skipped_last && slow) {
-            // the launch left the kernels behind the wave decoder out and a stream needed them after all: now, then the rows once more
+        if (slow) {
+            // a row still SLOWPATH on a plan that is not WAVEONLY: the launch left the kernels behind the wave decoder out (the lazy skip) and a
+            // stream needed them after all -- or the rows come from a launch this call cannot see into (a graph captured earlier): now, then
+            // the rows once more.  (Behind a launch that did carry them no row is SLOWPATH: the fallback kernel takes whatever is left.)
             HIP_TRY(sqoa_launch_decode_standby(p->d_jobs, p->d_ids, p->n_sqoa, p->small, ((p->shape | (p->n_chain_b > 0 ? p->shape_b : 0)) & 8) ? 1 : 0, p->d_results, p->stream), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipStreamSynchronize(p->stream), SQOA_HIP_ELAUNCH);
             HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
             p->lazy_skip = false; p->skipped_last = false;
-        } else if (n == p->n && lazy) p->lazy_skip = !used && !slow;   // (a full view of the launch: no job took them -- the next launch does without)
+        } else if (n == p->n && lazy) p->lazy_skip = !used;   // (a full view of the launch: no job took them -- the next launch does without)
     }
+    // (the stand-by marker lives in the pad byte behind sqoa_desc's three flags: the plan's business, not the caller's)
+    for (int i = 0; i < n; ++i) reinterpret_cast<unsigned char*>(&out[i].desc)[11] = 0;
     return 0;
 }
 

@@ -1,5 +1,7 @@
 """GPU parity: the HIP decoder behind the C-ABI vs golden vectors and the oracle."""
 import numpy as np
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -281,30 +283,41 @@ def test_full_headline_batch_roundtrip(sq, orc, synth_digests):
         del dec, enc
 
 
-@pytest.mark.parametrize("rank", [0, 3, 7])
+@pytest.mark.parametrize("rank", list(range(8)))
 def test_c5_rank_of_8_shard(sq, orc, rank):
-    """BASELINE configs[4] as the first, a middle and the last of its 8 ranks see it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py),
-    LPT-sharded on w*h, the rank's 8 192 images in ONE encode plan and ONE decode plan (the workload class of
-    `bench.py --config c5 --gpus 8`): every status OK, every image round-trips exactly (sqoabench.c:448-455, one result per
-    image as in sqoabench.c:575-628), and a sample of streams from every directory is byte-equal to the oracle's."""
+    """BASELINE configs[4] as EVERY one of its 8 ranks sees it: the qoi-suite-shaped list of 65 536 images (seqoia_amd/suite.py), LPT-sharded
+    on w*h, the rank's 8 192 images in ONE encode plan and ONE decode plan (the workload class of `bench.py --config c5 --gpus 8`): every
+    status OK, every image round-trips exactly (sqoabench.c:448-455, one result per image as in sqoabench.c:575-628), and EVERY stream is
+    pinned to the compiled reference's (seqoia.h:456-650) by length and FNV-1a-64 -- tests/golden/c5_digests.npz, all 65 536 images, written
+    by oracle/make_golden.py --c5; the digests here computed on the device -- plus one stream per directory byte for byte."""
+    import numpy as np
     import torch
 
     import bench
+    from conftest import GOLDEN
     from seqoia_amd import suite
 
+    gold = np.load(os.path.join(GOLDEN, "c5_digests.npz"))
+    assert int(gold["count"]) == suite.C5_IMAGES and int(gold["seed"]) == 1
     shard = suite.shard(suite.C5_IMAGES, 8, rank)
     assert len(shard) > 8000
     wl = bench.Suite(sq, torch, torch.device("cuda", 0), shard)  # asserts statuses and the round trip of every image
     assert wl.pixels == sum(im.pixels for im in shard)
     streams_at = wl.enc.offsets
+    idx = np.array([im.index for im in shard])
+    assert (wl.lens == gold["lens"][idx].astype("int64")).all(), "stream lengths differ from the reference's"
+    base = wl.enc.out.data_ptr()
+    got = np.array(sq.fnv1a64([base + o for o in streams_at[:-1]], wl.lens.tolist()), dtype=np.uint64)
+    bad = np.nonzero(got != gold["fnv"][idx])[0]
+    assert bad.size == 0, [shard[i] for i in bad[:4]]
     o = orc.best()
     seen = set()
     for i, im in enumerate(shard):
         if im.directory in seen or im.pixels > 2_000_000:
             continue
         seen.add(im.directory)
-        got = bytes(wl.enc.out[streams_at[i] : streams_at[i] + int(wl.lens[i])].cpu().numpy())
-        assert got == o.encode(orc.synth(im.width, im.height, im.channels, im.cls, 1, im.index), im.width, im.height, im.channels, 0), im
+        got1 = bytes(wl.enc.out[streams_at[i] : streams_at[i] + int(wl.lens[i])].cpu().numpy())
+        assert got1 == o.encode(orc.synth(im.width, im.height, im.channels, im.cls, 1, im.index), im.width, im.height, im.channels, 0), im
     assert len(seen) >= 12
     wl.step(0)  # the timed step of bench.py is repeatable: same lengths after a second encode + decode
     torch.cuda.synchronize()
@@ -312,25 +325,37 @@ def test_c5_rank_of_8_shard(sq, orc, rank):
     wl.close()
 
 
-def test_c4_icon_set_at_full_size(sq, orc):
-    """BASELINE configs[3] at its full size: 4 096 icon-style RGB images of 512 x 512 (RUN / BIGRUN dominated; the plan takes the wave
-    decoder's position-major store shape for them) in one encode plan and one decode plan per output channel count: every status OK,
-    every image round-trips exactly to three channels and to four (sqoabench's timed decode, sqoabench.c:490-494), every stream's length
-    and a sample of 32 streams spread over the set byte-equal to the compiled reference's, in both wire formats."""
+@pytest.mark.parametrize("size", [64, 128, 256, 512])
+def test_c4_icon_set_at_full_size(sq, orc, size):
+    """BASELINE configs[3] at its full size: 4 096 icon-style RGB images of 64^2, 128^2, 256^2 and 512^2 (RUN / BIGRUN dominated; the plan takes
+    the wave decoder's position-major store shape for the large ones) in one encode plan and one decode plan per output channel count, in both
+    wire formats: every status OK, EVERY stream pinned to the compiled reference's by length and FNV-1a-64 (tests/golden/c4_digests.npz: 4 sizes
+    x 4 096 images x 2 formats, written by oracle/make_golden.py --c4; the digests here computed on the device), every image round-trips
+    exactly to three channels and to four (sqoabench's timed decode, sqoabench.c:490-494), and 8 streams spread over the set byte for byte."""
+    import numpy as np
     import torch
 
-    n, w, h, ch = 4096, 512, 512, 3
+    from conftest import GOLDEN
+
+    gold = np.load(os.path.join(GOLDEN, "c4_digests.npz"))
+    si = gold["sizes"].tolist().index(size)
+    n, w, h, ch = 4096, size, size, 3
+    assert gold["lens"].shape == (4, 2, n) and int(gold["channels"]) == ch and int(gold["seed"]) == 1
     px = torch.empty((n, h, w, ch), dtype=torch.uint8, device="cuda")
     sq.synth(px, "icon", seed=1, img0=0)
     o = orc.best()
-    sample = list(range(0, n, n // 32))
+    sample = list(range(0, n, n // 8))
     for mode in (0, 1):
         enc = sq.EncodePlan(px, qoi_compat=mode)
         enc.launch()
         res = enc.results()
         assert (res["status"] == 0).all()
-        got = enc.streams(sample)
-        for k, g in zip(sample, got):
+        assert (res["len"].astype("int64") == gold["lens"][si, mode].astype("int64")).all(), (size, mode, "stream lengths differ from the reference's")
+        base = enc.out.data_ptr()
+        got = np.array(sq.fnv1a64([base + i * enc.slot for i in range(n)], res["len"].tolist()), dtype=np.uint64)
+        bad = np.nonzero(got != gold["fnv"][si, mode])[0]
+        assert bad.size == 0, (size, mode, bad[:8].tolist())
+        for k, g in zip(sample, enc.streams(sample)):
             assert g == o.encode(orc.synth(w, h, ch, "icon", 1, k), w, h, ch, mode), (mode, k)
         for oc in (3, 4):
             dec = sq.DecodePlan(enc.out, res["len"], w, h, oc)
@@ -908,6 +933,100 @@ def test_speculative_qoi_route_finds_stale_index_entries(sq, orc, monkeypatch):
             assert res["status"][i] == 0 and res["len"][i] == N * oc, (oc, i)
             assert out[i].tobytes() == want.tobytes(), (oc, i)
         dec.close()
+
+
+def test_launches_behind_results_keep_decoding(sq, orc):
+    """The plan's lazy skip (sqoa_runtime.hip: once a launch's result rows say that no job needed the kernels behind the wave decoder, the
+    next launches leave them out) must leave out THOSE kernels and nothing else.  Round 5's version also switched off the speculative
+    chip-wide pass of multi-pass QOI-compat streams, whose rows never say "stand-by used": every launch behind a results() call left such a
+    stream undecoded, and results() repaired it with the one-workgroup kernel -- invisible to a caller who reads pixels after a stream
+    synchronise, or replays a graph.  Here: launch, results(), zero the output, launch again, synchronise, compare the pixels BEFORE
+    results() is asked; then the same through plan.time() (what bench.py's secondary rows do)."""
+    import torch
+
+    w = h = 1024
+    for cls, ch, qoi in (("photo", 3, 1), ("mixed", 4, 1), ("mixed", 4, 0)):
+        px = torch.empty((1, h, w, ch), dtype=torch.uint8, device="cuda")
+        sq.synth(px, cls, seed=9, img0=2)
+        enc = sq.EncodePlan(px, qoi_compat=qoi)
+        enc.launch()
+        res = enc.results()
+        assert res["status"][0] == 0
+        dec = sq.DecodePlan(enc.out, res["len"], w, h, ch)
+        dec.launch()
+        assert dec.results()["status"][0] == 0 and torch.equal(dec.out, px)
+        for _ in range(3):   # (round 5 alternated: skip, repair, skip, ...)
+            dec.out.zero_()
+            torch.cuda.synchronize()
+            dec.launch()
+            torch.cuda.synchronize()
+            assert torch.equal(dec.out, px), (cls, ch, qoi, "a launch behind results() left the stream undecoded")
+            assert dec.results()["status"][0] == 0
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        dec.time(3)
+        torch.cuda.synchronize()
+        assert torch.equal(dec.out, px), (cls, ch, qoi, "timed launches decode nothing")
+        dec.close()
+        enc.close()
+
+
+def test_a_graph_captured_behind_results_keeps_the_standby_kernels(sq, orc):
+    """A launch captured into a graph AFTER results() has told the plan that nobody needed the kernels behind the wave decoder must still
+    carry them: the graph outlives that knowledge.  Replayed over a stream that needs them (an SQOA_OP_REF patched into the same buffer,
+    seqoia.h:729-738: the exact decoder's business), the pixels must be the reference's -- and results() must say OK, not SLOWPATH."""
+    import torch
+
+    w, h = 256, 256
+    px = torch.empty((4, h, w, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(px, "mixed", seed=3, img0=0)
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    enc.launch()
+    res = enc.results()
+    assert (res["status"] == 0).all()
+    o = orc.best()
+    streams = enc.streams()
+    # a patched copy of stream 2 that the reference still decodes (a REF op somewhere in the middle)
+    patched, want = None, None
+    for pos in range(len(streams[2]) // 2, len(streams[2]) // 2 + 400):
+        cand = bytearray(streams[2]); cand[pos] = 0x45
+        got = o.decode(bytes(cand), 4)[0]
+        if got is not None and got.tobytes() != px[2].cpu().numpy().tobytes():
+            patched, want = bytes(cand), got
+            break
+    assert patched is not None
+    buf = enc.out.clone()
+    dec = sq.DecodePlan(buf, res["len"], w, h, 4)
+    dec.launch()
+    assert (dec.results()["status"] == 0).all() and torch.equal(dec.out, px)   # (from here on the plan's own launches skip the stand-by kernels)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dec.launch(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        dec.launch(side.cuda_stream)
+    buf[2, : len(patched)] = torch.frombuffer(bytearray(patched), dtype=torch.uint8).cuda()
+    for _ in range(2):
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert dec.out[2].cpu().numpy().tobytes() == want.tobytes(), "the replayed graph left the REF stream to nobody"
+        assert torch.equal(dec.out[0], px[0]) and torch.equal(dec.out[3], px[3])
+        r = dec.results()
+        assert (r["status"] == 0).all() and (r["pad"] == 0).all()
+    # ... and the plan's own launches find their way as well (results() repairs the first, the next carries the kernels again)
+    for _ in range(2):
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        dec.launch()
+        assert (dec.results()["status"] == 0).all()
+        assert dec.out[2].cpu().numpy().tobytes() == want.tobytes()
+    dec.close()
+    enc.close()
 
 
 @pytest.mark.parametrize("cls,ch", [("mixed", 4), ("mixed", 3), ("photo", 3)])

@@ -116,3 +116,38 @@ def test_headline_digest_table_is_consistent():
         px = po.synth(1024, 1024, 4, "mixed", 1, img)
         s, q = orc.encode(px, 1024, 1024, 4, 0), orc.encode(px, 1024, 1024, 4, 1)
         assert rows[img] == [len(s), f"{po.fnv1a64(s):016x}", len(q), f"{po.fnv1a64(q):016x}"]
+
+
+def test_c4_and_c5_digest_tables_against_the_restatement():
+    """tests/golden/c4_digests.npz / c5_digests.npz (every stream of BASELINE configs[3] and configs[4], from the compiled reference:
+    oracle/make_golden.py --c4 --c5): shape and totals, and the CPU restatement on a seeded sample of both -- the icon sets at every
+    size in both wire formats, and suite images of every directory but the screenshot-sized ones."""
+    import os
+
+    from conftest import GOLDEN
+    from seqoia_amd import suite
+
+    orc = po.restatement()
+    c4 = np.load(os.path.join(GOLDEN, "c4_digests.npz"))
+    assert c4["sizes"].tolist() == [64, 128, 256, 512] and c4["lens"].shape == (4, 2, 4096) and c4["fnv"].shape == (4, 2, 4096)
+    rng = np.random.default_rng(4)
+    for si, size in enumerate(c4["sizes"].tolist()):
+        for img in rng.integers(0, 4096, 6).tolist():
+            px = po.synth(size, size, 3, "icon", 1, img)
+            for mode in (0, 1):
+                s = orc.encode(px, size, size, 3, mode)
+                assert (len(s), po.fnv1a64(s)) == (int(c4["lens"][si, mode, img]), int(c4["fnv"][si, mode, img])), (size, img, mode)
+    c5 = np.load(os.path.join(GOLDEN, "c5_digests.npz"))
+    imgs = suite.images(suite.C5_IMAGES)
+    assert c5["lens"].shape == (65536,) and c5["fnv"].shape == (65536,) and int(c5["count"]) == len(imgs)
+    seen = {}
+    for k in rng.permutation(len(imgs)).tolist():
+        im = imgs[k]
+        if im.pixels > 1_500_000 or seen.get(im.directory, 0) >= 2:
+            continue
+        seen[im.directory] = seen.get(im.directory, 0) + 1
+        s = orc.encode(po.synth(im.width, im.height, im.channels, im.cls, 1, im.index), im.width, im.height, im.channels, 0)
+        assert (len(s), po.fnv1a64(s)) == (int(c5["lens"][k]), int(c5["fnv"][k])), im
+        if len(seen) >= 11 and all(v >= 2 for v in seen.values()):
+            break
+    assert len(seen) >= 11
