@@ -164,6 +164,13 @@ void *sqoa_hip_plan_stream(sqoa_hip_plan *plan);
  * stream).  Asynchronous; no allocation, no host sync: graph-capturable. */
 int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 
+/* Diagnostic (tests, tools): the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each -- decode plans: bit 0 many
+ * short streams, bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance.
+ * A decode plan that took the balanced kernel drops it from the launch after sqoa_hip_plan_results has seen, in a full view of a launch's rows,
+ * that most of its pixels come from streams that kernel is slow on (two-byte ops throughout: photographs; or more op starts in a chunk than it has
+ * slots: ramps, flat images) -- the kernels report what they saw in the rows; SQOA_HIP_DEC_CONTENT=0 in the environment keeps the first choice. */
+int sqoa_hip_plan_shape(const sqoa_hip_plan *plan);
+
 /* Wait for the plan's most recent launch and copy the n results to host memory.  This call is what makes a launch's statuses and
  * lengths FINAL: a decode plan launches two more kernels behind its wave decoder (QOI-compat streams, mono streams, 1- / 2-channel
  * output, SQOA_OP_REF; behind the balanced kernel a third in front of them, for streams with more op starts in a 1024-byte chunk than

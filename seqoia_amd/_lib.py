@@ -76,6 +76,7 @@ SYMBOLS = {
     "sqoa_hip_memcpy_h2d_async": (C.c_int, [C.c_int, C.c_ulonglong, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sqoa_hip_memcpy_d2h_async": (C.c_int, [C.c_int, C.c_void_p, C.c_ulonglong, C.c_size_t, C.c_void_p]),
     "sqoa_hip_plan_stream": (C.c_void_p, [C.c_void_p]),
+    "sqoa_hip_plan_shape": (C.c_int, [C.c_void_p]),
     "sqoa_hip_encode_route": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sqoa_hip_decode_route": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sqoa_hip_plan_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(Job), C.c_int, C.POINTER(C.c_void_p)]),

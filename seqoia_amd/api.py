@@ -110,6 +110,10 @@ class Plan:
                        ("colorspace", "u1"), ("qoi_compat", "u1"), ("pad", "u1")])
         return np.frombuffer(bytes(res), dtype=dt, count=self.n).copy()
 
+    def shape(self) -> int:
+        """sqoa_hip_plan_shape: the kernel shape the next launch takes (decode plans; bit 3 = the balanced kernel)."""
+        return self.lib.sqoa_hip_plan_shape(self._h)
+
     def time(self, iters: int) -> float:
         """Milliseconds for `iters` back-to-back launches, HIP events on the plan's own stream."""
         ms = C.c_float(0)

@@ -92,7 +92,20 @@ constexpr int kHeader = 14;                // reference seqoia.h:425
 // The unused fourth byte behind sqoa_desc's three flags in a result row: 1 = one of the kernels BEHIND the wave decoder took this job in the
 // launch that wrote the row (reset by the wave decoder with the row).  The plan reads it with the rows: a decode plan none of whose jobs needed
 // those kernels does not launch them the next time (sqoa_runtime.hip, sqoa_hip_plan_results).
-SQOA_DEV void row_mark_standby(sqoa_hip_result* res, uint8_t v) { reinterpret_cast<volatile uint8_t*>(&res->desc)[11] = v; }
+// Bits 1..7 of the same byte, set by the balanced decoder (sqoa_decode_bal.hip) and read by the plan with the rows: what the stream's CONTENT looks
+// like to that kernel -- 0 = nothing said; 1..126 = op starts per 1024-byte chunk / 4, averaged over a sample of the stream's chunks (ops of two
+// bytes throughout -- photographs -- make 512 starts a chunk: every lane owns exactly eight ops, its LDS accesses fall on a quarter of the banks
+// and decode_wave_kernel is the faster kernel: DESIGN.md 3.2c); 127 = a chunk held more starts than the kernel has slots (the stream went to the
+// retry).  A plan whose launches mostly see such streams takes decode_wave_kernel from the next launch on (sqoa_runtime.hip, sqoa_hip_plan_results).
+constexpr uint32_t ROW_HINT_SHIFT = 25;   // (bit 1 of byte 11 of sqoa_desc = bit 25 of its third dword)
+SQOA_DEV void row_mark_standby(sqoa_hip_result* res, uint8_t v) {
+    volatile uint8_t* b = reinterpret_cast<volatile uint8_t*>(&res->desc) + 11;
+    if (v) *b = (uint8_t)(*b | 1u);   // (the kernels behind the wave decoder run in later launches of the stream: nobody else is writing the row)
+    else *b = 0;
+}
+SQOA_DEV void row_content_hint(sqoa_hip_result* res, uint32_t hint) {
+    atomicOr(reinterpret_cast<uint32_t*>(&res->desc) + 2, (hint & 127u) << ROW_HINT_SHIFT);
+}
 
 SQOA_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -120,6 +133,27 @@ SQOA_DEV uint32_t wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 8, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xa, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+
+// The same, hand-written: six v_add_u32_dpp.  The compiler fuses the DPP move into the add only where it can see that the move's `old` operand is the
+// add's identity; where the zero is a hoisted register copy (the balanced decoder's rank scan) it emits v_mov + v_mov_dpp + v_add per step -- three
+// slow-class instructions for one.  (A VALU write of a VGPR wants two wait states in front of a DPP read of it: the s_nop 1.)
+SQOA_DEV uint32_t wave_incl_scan_dpp(uint32_t v) {
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 

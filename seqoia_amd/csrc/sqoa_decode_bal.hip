@@ -213,6 +213,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const uint32_t area = chunks_len > p0 ? chunks_len - p0 : 0;
     const uint32_t nchunks = area ? (area + CHUNK - 1) / CHUNK : 1;
     uint32_t bad = 0;
+    uint32_t ops_seen = 0;   // the content sample for the plan: sum of op starts (20 bits) | chunks counted << 20
 
 #ifdef SQOA_TRACE  // diagnostic builds: where wave 0 spends its time, written behind the image's pixels (dst_cap must allow it)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
@@ -314,10 +315,14 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             // An exit state that does not depend on the entry state is posted before the entry state is known; the two-deep slots are safe
             // because the pixel chain below holds a wave back (it cannot finish chunk c + W before chunk c + 1 has been entered).
             if (g_const && !last_chunk) post(my_parse, c + 1, g0, lane);
+#ifdef SQOA_DBG_BAL_NOCHAIN   // timing experiments only (wrong output): nothing is waited for -- what do the chains cost?
+            if (c > 0) st_in = S_A;
+#else
             if (c > 0) {
                 const uint32_t rc = chain_wait_rc<SPIN>(&s_parse[((c - 1) / W) & 1][(c - 1) % W], c, st_in);
                 if (rc) { bad |= rc >> 1; return 0u; }
             }
+#endif
             if (!g_const && !last_chunk) post(my_parse, c + 1, apply(G, st_in), lane);
         }
         BPHASE(1);
@@ -370,15 +375,24 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             M = (m8lo | m8hi << 8) >> 3;   // (the flags are 0x08 per byte)
         }
         const uint32_t n_lane = (uint32_t)__builtin_popcount(M);
+#ifndef SQOA_BAL_SCAN_DPP   // the rank scan as six v_add_u32_dpp (sqoa_common.h): the compiler's form of it is 17 instructions
+#define SQOA_BAL_SCAN_DPP 1
+#endif
+#if SQOA_BAL_SCAN_DPP
+        const uint32_t rinc = wave_incl_scan_dpp(n_lane);
+#else
         const uint32_t rinc = wave_incl_scan(n_lane);
+#endif
         const uint32_t n_ops = bcast_lane(rinc, 63);
         // (more than 64 R walk iterations in a chunk: two starts are two bytes apart or more on average unless one-byte ops that nothing takes
         // along follow each other -- SQOA_OP_REF bytes, which hand the stream over anyway, but also RUN behind RUN (flat regions: BIGRUN bytes on
         // end), and 512 two-byte ops plus ONE one-byte op are 513.  The stream goes to the retry behind this launch: the file's head.)
         if (n_ops > 64u * R) {   // (before the list is written: it has room for 64 R starts)
-            if (lane == 0) atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH);
+            if (lane == 0) { atomicMax(&res->status, SQOA_HIP_ST_SLOWPATH); row_content_hint(res, 127u); }
             return 0u;
         }
+        // what the content looks like, for the plan (row_content_hint, sqoa_common.h): op starts per chunk over the first 256 chunks of wave 0's
+        if (c < 2048u) ops_seen += n_ops + (1u << 20);
         {
             // Every start's byte offset to the list at its rank.  Hand-written: per start the compiler's loop was a wave vote, two compares, a
             // select and four scalar instructions around the five that do the work.  Here a lane that has run out of starts leaves EXEC
@@ -537,7 +551,12 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const Xf Tx{shift_up1(Ti.v, 0u), shift_up1(Ti.abs, 0u)};
             // ---- entry position / pixel from the chain, publish exits, store ------------------
             {
+#ifdef SQOA_DBG_BAL_NOCHAIN
+                if (c > 0) { pos_in = c * 400u; asm volatile("" : "+s"(pos_in)); }
+                if (false) {
+#else
                 if (c > 0) {
+#endif
                     // one wait for both: the position word is written before the pixel word by the same lane (LDS executes a wave's
                     // instructions in order), so it is there when the pixel word's tag is
                     const uint32_t rc = chain_wait_rc<SPIN>(&s_px[(c - 1) % W], c, px_in);
@@ -756,6 +775,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         __hip_atomic_store(&s_px[w], gone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (bad && lane == 0) atomicMax(&res->status, SQOA_HIP_ST_INTERNAL);
+    if (w == 0 && lane == 0 && go && (ops_seen >> 20) >= 4u) {   // (a stream of a few chunks says nothing)
+        const uint32_t avg = (ops_seen & 0xfffffu) / (ops_seen >> 20);
+        row_content_hint(res, 1u + (avg >> 2 > 125u ? 125u : avg >> 2));
+    }
 #ifdef SQOA_TRACE
     __syncthreads();
     if (threadIdx.x == 0) {

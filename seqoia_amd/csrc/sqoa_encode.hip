@@ -93,6 +93,56 @@ SQOA_DEV uint32_t chain_wait(unsigned long long* slot, uint32_t tag, EncState& s
 
 SQOA_DEV void chain_post(unsigned long long* slot, uint32_t tag, uint32_t val, int lane) { lds_post(slot, tag, val, lane); }
 
+#ifndef SQOA_ENC_LOOKBACK   // 1: the byte-position chain as a decoupled look-back (below) -- built, byte-exact on the whole suite, measured, NOT taken:
+#define SQOA_ENC_LOOKBACK 0 // headline 1.512 -> 1.538 ms, QOI-compat 2.280 -> 2.360, icons 1.377 -> 1.422, photo RGB 1.250 -> 1.285 (same-call A/B, round 6)
+#endif
+// The byte position of sub-tile j's first byte (j >= 1) by DECOUPLED LOOK-BACK (round 6; an experiment that answered a question -- see the flag).
+// The kernel hands the position from sub-tile to sub-tile: wave j % W waits for sub-tile j - 1's word, adds its own byte count, posts -- a serial
+// chain of 2 048 hops through a 1 Mpixel image; wave 0 spends a third of its life in that wait (tools/trace_encode.py), and the kernel hardly
+// cares how many instructions the rest of the loop takes (round 6: the whole cross-lane run fix-up removed, a sixth of the VALU instructions,
+// bought 2.8 %).  Is the chain the bound, then?  Here every sub-tile publishes its byte COUNT (`agg`) the moment it is known -- before anything is
+// waited for -- and its inclusive position (`pos`) when it has one; a wave that needs its position looks at the W sub-tiles in front of it at
+// once (lanes 0..7: their positions, lanes 8..15: their counts, one ds_read_b64), takes the nearest position that is there and adds the counts
+// of the sub-tiles in between: nobody waits for a predecessor to be SCHEDULED, only for counts, which all W waves of an image produce side by
+// side.  Its own previous sub-tile's position (j - W) is always there, so the look-back ends as soon as the W - 1 counts in between are.
+// Answer: no.  1.7 - 3.5 % SLOWER on every workload: the wait is slack -- time a wave gives to the 31 others of its compute unit while the
+// board sits at its power cap --, not a critical path, and the look-back's two dozen instructions per poll are not free.
+// Two-deep slots ([(sub-tile / W) & 1][sub-tile % W]): sub-tile j's count is overwritten by j + 2W's, which its wave produces after it has
+// flushed j + W -- by then everybody who might want it finds j's POSITION (posted before j was flushed) and stops there; j's position is
+// overwritten by j + 2W's, which needs the counts of j + W + 1 .. j + 2W - 1, whose waves have resolved j + 1 .. j + W - 1 before they got there.
+template <int W>
+SQOA_DEV uint32_t pos_lookback(const unsigned long long (*s_pos)[W], const unsigned long long (*s_agg)[W], uint32_t j, EncState& st) {
+    static_assert(W <= 8, "one lane per sub-tile looked at");
+    uint32_t lane;   // (recomputed: everything derived from the kernel's `lane` is a loop invariant the compiler keeps, or spills)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const uint32_t i = lane & 7u;          // this lane looks at sub-tile t = j - 1 - i (i >= j wraps: no tag is that large)
+    const uint32_t t = j - 1u - i;
+    const bool is_pos = lane < 8u;
+    const uint32_t slot = ((t / (uint32_t)W) & 1u) * (uint32_t)W + t % (uint32_t)W;
+    const uint32_t addr = (is_pos ? (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned long long*)&s_pos[0][0]
+                                  : (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned long long*)&s_agg[0][0]) + 8u * slot;
+    const bool mine = lane < 16u && i < (uint32_t)W && i < j;
+    for (uint32_t spin = 0; spin < SPIN_MAX; ++spin) {
+        unsigned long long word;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(word) : "v"(addr) : "memory");
+        const uint32_t val = (uint32_t)word, tag = (uint32_t)(word >> 32);
+        const uint32_t ok = (uint32_t)__ballot(mine && tag == t + 1u);   // (lanes 0..15 only: the mask's low half)
+        const uint32_t mP = ok & 0xffu, mA = ok >> 8;
+        if (mP) {
+            const uint32_t kP = (uint32_t)__builtin_ctz(mP);               // the nearest sub-tile whose position is there: j - 1 - kP
+            const uint32_t need = (1u << kP) - 1u;                        // the counts of the sub-tiles in between
+            if ((mA & need) == need) {
+                uint32_t pos = bcast_lane(val, (int)kP);
+                for (uint32_t m = need; m; m &= m - 1u) pos += bcast_lane(val, 8 + __builtin_ctz(m));
+                return pos;
+            }
+        }
+        if (st.eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(SQOA_ENC_SPIN_SLEEP);
+    }
+    st.bad = 1;
+    return 0;
+}
+
 // Op bytes of a pixel that differs from its predecessor (reference seqoia.h:584-635),
 // little-endian in lo (bytes 0-3) / hi (byte 4).  QOI index hits are patched in by the caller.
 template <bool QOI>
@@ -605,7 +655,12 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     __shared__ __attribute__((aligned(16))) uint8_t s_pre[QL8 ? 2 * W : W][ENC_PRE];
     __shared__ __attribute__((aligned(16))) uint8_t s_hit[QL8 ? W : 1][QL8 ? ENC_SUB : 16];
     __shared__ unsigned long long s_run[2][W];
+#if SQOA_ENC_LOOKBACK
+    __shared__ unsigned long long s_pos[2][W];   // [(sub-tile / W) & 1][sub-tile % W]: tag = sub-tile + 1 | the position BEHIND its last byte
+    __shared__ unsigned long long s_agg[2][W];   // ... | its byte count (pos_lookback)
+#else
     __shared__ unsigned long long s_pos[W];
+#endif
     // QOI colour index (seqoia.h:563-582): per-wave working table, last-writer stamps and per-slot lane
     // masks, plus each wave's published end-of-sub-tile table (double-buffered by tile parity)
     constexpr int QW = QOI ? W : 1;
@@ -655,7 +710,11 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
     constexpr uint32_t M = QOI ? 62u : 512u;  // seqoia.h:411-412
 
     const lptr8 stage = (lptr8)s_stage[w];
+#if SQOA_ENC_LOOKBACK
+    if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[0][w] = 0; s_pos[1][w] = 0; s_agg[0][w] = 0; s_agg[1][w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
+#else
     if (lane == 0) { s_run[0][w] = 0; s_run[1][w] = 0; s_pos[w] = 0; s_tabtag[0][w] = 0; s_tabtag[1][w] = 0; }
+#endif
     if (QOI) { s_tabw[w % QW][lane] = 0; s_stamp[w % QW][lane] = 0; s_smask[w % QW][lane] = 0; if (QL8) s_last[w % QLW][lane] = 0; }
     if (QOI && SQOA_ENC_Q_RTN) s_pstamp[w % QW][lane] = 0;
     if (QL8 && SQOA_ENC_Q_RTN == 3) s_pst64[w % QW][lane] = 0;
@@ -977,6 +1036,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 ((lptr32)stage)[2] = b9;
             }
             sbase = nbytes;
+#if SQOA_ENC_LOOKBACK
+            chain_post(&s_agg[(j / W) & 1][w], j + 1, sbase, lane);
+#endif
         } else if (swar) {
             sbase = swar_emit<QOI>(cur, grp, E, c_in, pa, has_after, eof, stage, lane, le_mask, tabw, smask, pstamp, qrow64);
         } else {
@@ -1077,9 +1139,16 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
 
         PHASE(4);
         // ---- output position from the chain, then drain the staging buffer -------------
+#if SQOA_ENC_LOOKBACK
+        if (!last_sub) chain_post(&s_agg[(j / W) & 1][w], j + 1, sbase, lane);   // my byte count, before anything is waited for
+        const uint32_t pos = j == 0 ? hdr_len : pos_lookback<W>(s_pos, s_agg, j, st);
+        PHASE(5);
+        if (!last_sub) chain_post(&s_pos[(j / W) & 1][w], j + 1, pos + sbase, lane);
+#else
         const uint32_t pos = j == 0 ? hdr_len : chain_wait<QOI>(&s_pos[(j - 1) % W], j, st);
         PHASE(5);
         if (!last_sub) chain_post(&s_pos[w], j + 1, pos + sbase, lane);
+#endif
         flush_stage(stage, sbase, dst + pos, lane);
         PHASE(6);
         if (last_sub) {  // seqoia.h:644-649
@@ -1128,9 +1197,21 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             dif = (R0 ^ (pb & 255u) * m) | (G0 ^ ((pb >> 8) & 255u) * m) | (B0 ^ ((pb >> 16) & 255u) * m) |
                   (R1 ^ (pb & 255u) * m) | (G1 ^ ((pb >> 8) & 255u) * m) | (B1 ^ ((pb >> 16) & 255u) * m);
         } else {
+#ifndef SQOA_ENC_DIF_LAZY   // "is the whole sub-tile one run" from the lanes' FIRST pixels, and only where those all repeat from the other seven
+#define SQOA_ENC_DIF_LAZY 1
+#endif
+#if SQOA_ENC_DIF_LAZY
+            dif = cur[0] ^ pb;
+            asm volatile("" : "+v"(dif));
+            if (__ballot(dif != 0u) == 0ull) {
+#pragma unroll
+                for (int s = 1; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+            }
+#else
             dif = 0;
 #pragma unroll
             for (int s = 0; s < ENC_S; ++s) dif |= cur[s] ^ pb;
+#endif
         }
         asm volatile("" : "+v"(dif));
         const bool flat = __ballot(dif != 0u) == 0ull;
@@ -1150,6 +1231,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             if (r != 0u && pa != pb) { last = 0xc0u | (r - 1u); nbytes = nfd + 1u; }
             if ((uint32_t)lane < nbytes) stage[lane] = (uint32_t)lane < nfd ? (uint8_t)0xfd : (uint8_t)last;   // (the buffer is zeroed, position-independent)
             sbase = nbytes;
+#if SQOA_ENC_LOOKBACK
+            chain_post(&s_agg[(j / W) & 1][w], j + 1, sbase, lane);
+#endif
             qoi_table_hop(j, false, [](unsigned long long*) {});
         } else if (flat) {
             const uint32_t c_in = chain_wait<QOI>(prev_run, j, st);
@@ -1174,6 +1258,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 ((lptr32)stage)[2] = b9;
             }
             sbase = nbytes;
+#if SQOA_ENC_LOOKBACK
+            chain_post(&s_agg[(j / W) & 1][w], j + 1, sbase, lane);
+#endif
         } else {
             const uint32_t ONE = 0x01010101u;
             uint32_t Hv, L7;  // the two SWAR constants in VGPRs
@@ -1399,6 +1486,28 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 // the sub-tile pixel index of the last pixel below my stretch that does NOT repeat: a running maximum over the lanes
                 // (one v_max_i32 per DPP step), -1 if every pixel below repeats (the run then comes from before the sub-tile)
                 const int hb = 7 - (int)__builtin_clz((nE & 0xffu) << 24);                            // my own last such pixel; clz(0) = 32: none
+#ifndef SQOA_ENC_MAXSCAN_U   // the running maximum over index + 1 (0: none) as six v_max_u32_dpp: zero is that maximum's identity, which lets the DPP move
+#define SQOA_ENC_MAXSCAN_U 1 // fold into the v_max (signed with -1 for "none" it is v_mov + v_mov_dpp + v_max_i32 per step)
+#endif
+#if SQOA_ENC_MAXSCAN_U
+                uint32_t lastne1 = E8 == 0xffu ? 0u : (uint32_t)(8 * lane + hb + 1);
+                asm("s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "s_nop 1\n\t"
+                    "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "s_nop 1"
+                    : "+v"(lastne1));
+                const uint32_t below1 = shift_up1(lastne1, 0u);                                        // exclusive: lanes below mine; 0: every pixel below repeats
+                const uint32_t carry = below1 ? 8u * (uint32_t)lane - below1 : 8u * (uint32_t)lane + c_in;
+#else
                 int lastne = E8 == 0xffu ? -1 : 8 * lane + hb;
                 lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 1, 0xf, 0xf, false));
                 lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_SHR + 2, 0xf, 0xf, false));
@@ -1408,6 +1517,7 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
                 lastne = max(lastne, __builtin_amdgcn_update_dpp(-1, lastne, DPP_ROW_BCAST31, 0xc, 0xf, false));
                 const int below_ne = __builtin_amdgcn_update_dpp(-1, lastne, DPP_WAVE_SHR1, 0xf, 0xf, false);   // exclusive: lanes below mine
                 const uint32_t carry = below_ne >= 0 ? (uint32_t)(8 * lane - 1 - below_ne) : 8u * (uint32_t)lane + c_in;
+#endif
                 // my leading run ends in my stretch iff a pixel of mine follows it, or (all eight repeat) the pixel after my last does not
                 const bool ends = (f - 1u < 7u) || (f == 8u && (l1 >> 24) != 0u);
                 // the run's remainder where it ends: k mod 512 (mod 62: QOI-compat, seqoia.h:411-412; there it is at most 61: one byte)
@@ -1445,6 +1555,9 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
             const uint32_t T0 = P0 >> 24, T = T0 + (P1 >> 24);
             const uint32_t incl = wave_incl_scan(T);
             sbase = bcast_lane(incl, 63);
+#if SQOA_ENC_LOOKBACK
+            chain_post(&s_agg[(j / W) & 1][w], j + 1, sbase, lane);   // the sub-tile's byte count: published before its bytes are staged, before anything is waited for
+#endif
             const uint32_t stage_addr = bcast_first((uint32_t)(uintptr_t)stage);
             // a lane without bytes ORs its zeros into a dword of its own (no 64 lanes on one LDS word in flat stretches)
             const uint32_t lb0 = T ? stage_addr + incl - T : stage_addr + 4u * lane, lb1 = lb0 + T0;
@@ -1490,9 +1603,15 @@ __global__ __launch_bounds__(W * 64) SQOA_ENC_WPE_ATTR void encode_kernel(const 
         cur_pb = nxt_pb.value();
         cur_pa = nxt_pa.value();
         PHASE(4);
+#if SQOA_ENC_LOOKBACK
+        const uint32_t pos = pos_lookback<W>(s_pos, s_agg, j, st);
+        PHASE(5);
+        chain_post(&s_pos[(j / W) & 1][w], j + 1, pos + sbase, lane);
+#else
         const uint32_t pos = chain_wait<QOI>(&s_pos[(j - 1) % W], j, st);
         PHASE(5);
         chain_post(&s_pos[w], j + 1, pos + sbase, lane);
+#endif
 #ifndef SQOA_DBG_NOFLUSH
 #ifdef SQOA_DBG_ALIGNED_POS   // timing experiments only (wrong output): every flush at a 16-byte-aligned address
         flush_stage(stage, sbase, dst + (pos & ~15u), lane);

@@ -131,6 +131,9 @@ struct sqoa_hip_plan {
     int small = 0;                      // decode: many short streams (more images than the chip holds large workgroups)
     int shape = 0;                      // decode, the streams that get a workgroup each: the wave decoder's shape (sqoa_launch_decode_wave) -- bit 0 = many short
                                         // streams, bit 1 = 12 stream bytes per lane, bit 2 = position-major stores
+    int shape_nobal = 0;                // decode: the shape the same streams get WITHOUT the balanced kernel -- taken from the launch after the one whose result
+                                        // rows say that the content is of the kind that kernel is slow on (row_content_hint, sqoa_common.h)
+    bool content_switched = false;
     int n_chain_b = 0, shape_b = 0;     // decode: the last n_chain_b of the streams that get a workgroup each are launched apart, with a shape of their own
                                         // (a plan of mixed output formats: its four-channel streams take the balanced kernel, the others what suits them)
     // decode, the two kernels behind the wave decoder (QOI-compat / mono / 1-2 channels / SQOA_OP_REF): launched with every launch until a launch's
@@ -505,7 +508,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             const char* kb = getenv("SQOA_HIP_DEC_BAL");
             // what the balanced kernel takes: four channels to a dword-aligned address, or three (round 5: 12-byte stores at any byte address)
             auto four = [&](int i) { return jobs[i].desc.channels == 3 || (jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull)); };
-            auto shape_of = [&](size_t a, size_t b) -> int {
+            auto shape_of = [&](size_t a, size_t b, bool allow_bal = true) -> int {
                 if (a >= b) return 0;
                 unsigned long long by = 0, by4 = 0, px = 0;
                 bool shaped = true, all4 = true, any3 = false;
@@ -528,10 +531,11 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                 //    whose every job is one of the two; a list to three channels alone keeps the wave decoder (SQOA_DEC_BAL_RGB above)
                 int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !p->small;
                 if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
-                bal = bal && all4;
+                bal = bal && all4 && allow_bal;
                 return p->small | wide << 1 | sweep << 2 | bal << 3 | (bal && any3 ? 1 : 0) << 4;   // (bit 4: the balanced kernel's instance that takes three-channel jobs)
             };
             p->shape = shape_of(c0, ids_a.size());
+            p->shape_nobal = shape_of(c0, ids_a.size(), false);
             p->n_chain_b = 0; p->shape_b = 0;
             // A list of mixed output formats (BASELINE configs[4]: 557 RGB photos to three channels among 7 635 RGBA images): the balanced kernel
             // is 12 % faster on the four-channel streams, which are most of such a list -- they go first, in a launch of their own, and the
@@ -556,6 +560,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
                     const int sa = shape_of(c0, c0 + a4.size());
                     if (sa & 8) {
                         p->shape = sa;
+                        p->shape_nobal = shape_of(c0, c0 + a4.size(), false);
                         p->shape_b = shape_of(c0 + a4.size(), ids_a.size());
                         p->n_chain_b = (int)rest.size();
                     } else std::copy(keep.begin(), keep.end(), ids_a.begin() + (long)c0);   // (the four-channel streams alone would not take it either)
@@ -564,6 +569,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         }
     }
     p->lazy_skip = p->skipped_last = p->launched = false;
+    p->content_switched = false;
     p->n = n;
     p->n_sqoa = (int)ids_a.size();
     p->n_qoi = (int)ids_b.size();
@@ -810,6 +816,10 @@ int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
 
 void* sqoa_hip_plan_stream(sqoa_hip_plan* p) { return p ? (void*)p->stream : nullptr; }
 
+// Diagnostic: the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each (decode plans; bit 0 many short streams,
+// bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance), -1 for no plan.
+int sqoa_hip_plan_shape(const sqoa_hip_plan* p) { return p ? p->shape : -1; }
+
 int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");
     HIP_TRY(hipSetDevice(p->device), SQOA_HIP_ENOGPU);
@@ -831,6 +841,28 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
             HIP_TRY(hipMemcpy(out, p->d_results, sizeof(sqoa_hip_result) * (size_t)n, hipMemcpyDeviceToHost), SQOA_HIP_ELAUNCH);
             p->lazy_skip = false; p->skipped_last = false;
         } else if (n == p->n && lazy) p->lazy_skip = !used;   // (a full view of the launch: no job took them -- the next launch does without)
+        // What the balanced kernel saw of the streams' CONTENT (row_content_hint, sqoa_common.h): where the jobs that make most of the plan's pixels
+        // are streams it is the slower kernel on -- 448 op starts or more per 1024-byte chunk: ops of two bytes throughout, photographs, every
+        // lane owns exactly eight ops and its LDS accesses fall on a quarter of the banks (class photo to four channels: 3.05 ms against
+        // decode_wave_kernel's 2.71) -- or streams with more op starts in a chunk than it has slots (ramps, flat images: they
+        // went through the retry), the plan's next launches take the shape the same list gets without it.  Decided ONCE per fill, from a full
+        // view of a launch's rows; SQOA_HIP_DEC_CONTENT=0 switches it off, a forced SQOA_HIP_DEC_BAL is not overruled.
+        if (n == p->n && (p->shape & 8) && !p->content_switched) {
+            const char* kc = getenv("SQOA_HIP_DEC_CONTENT");
+            const bool content = !(kc && kc[0] == '0');
+            unsigned long long px_said = 0, px_slow = 0;
+            for (int i = 0; i < n; ++i) {
+                const unsigned hint = reinterpret_cast<const unsigned char*>(&out[i].desc)[11] >> 1;
+                if (!hint || out[i].status != SQOA_HIP_ST_OK) continue;
+                const unsigned long long w = (unsigned long long)out[i].desc.width * out[i].desc.height;
+                px_said += w;
+                if (hint >= 1u + 448u / 4u) px_slow += w;   // (127: the slot overflow)
+            }
+            if (content && !getenv("SQOA_HIP_DEC_BAL") && px_said && 2 * px_slow >= px_said) {
+                p->shape = p->shape_nobal;
+                p->content_switched = true;
+            }
+        }
     }
     // (the stand-by marker lives in the pad byte behind sqoa_desc's three flags: the plan's business, not the caller's)
     for (int i = 0; i < n; ++i) reinterpret_cast<unsigned char*>(&out[i].desc)[11] = 0;

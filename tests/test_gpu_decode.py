@@ -783,6 +783,7 @@ def test_streams_with_more_op_starts_than_the_balanced_kernel_has_slots(sq, orc,
     import torch
 
     monkeypatch.setenv("SQOA_HIP_MULTIPASS", "0")
+    monkeypatch.setenv("SQOA_HIP_DEC_CONTENT", "0")   # (the plan would drop the balanced kernel after the first launch of such streams: the next test; here the retry is the subject)
     n, s = 64, 512
     x = torch.arange(s, device="cuda", dtype=torch.int32)
     row = (x & 255).to(torch.uint8)
@@ -811,6 +812,59 @@ def test_streams_with_more_op_starts_than_the_balanced_kernel_has_slots(sq, orc,
     assert ms < 5.0, ms   # (16.8 Mpixel: the balanced kernel as far as it gets + the retry; the exact decoder took 130 ms for these)
     dec.close()
     enc.close()
+
+
+def test_a_decode_plan_learns_from_the_content_its_launches_see(sq, orc, monkeypatch):
+    """What a plan can see without reading a stream -- sizes, channel counts -- does not tell photographs from screenshots, and the balanced
+    kernel (the plan's choice for large streams to four channels) is the slower one on ops of two bytes throughout (every lane owns exactly
+    eight ops: its LDS accesses fall on a quarter of the banks) and has to hand on streams with more op starts in a chunk than it has slots.
+    The kernel reports what it saw in the result rows (row_content_hint, sqoa_common.h) and sqoa_hip_plan_results, from a full view of a launch,
+    drops the balanced kernel for the NEXT launches where such streams are most of the plan's pixels: class photo and ramps switch, class mixed
+    stays; SQOA_HIP_DEC_CONTENT=0 and a forced SQOA_HIP_DEC_BAL keep the first choice; the pixels are the same throughout."""
+    import torch
+
+    monkeypatch.setenv("SQOA_HIP_MULTIPASS", "0")
+    n, s = 64, 512
+    x = torch.arange(s, device="cuda", dtype=torch.int32)
+    row = (x & 255).to(torch.uint8)
+    ramp = torch.stack([row, row, row, torch.full_like(row, 255)], dim=-1).expand(n, s, s, 4).contiguous()
+
+    def run(px, switches, env=()):
+        for k, v in env:
+            monkeypatch.setenv(k, v)
+        enc = sq.EncodePlan(px, qoi_compat=0)
+        enc.launch()
+        res = enc.results()
+        assert (res["status"] == 0).all()
+        dec = sq.DecodePlan(enc.out, res["len"], s, s, 4)
+        assert dec.shape() & 8, "large streams to four channels: the balanced kernel is the plan's first choice"
+        for launch in range(3):
+            dec.out.zero_()
+            torch.cuda.synchronize()
+            dec.launch()
+            torch.cuda.synchronize()
+            if launch:   # (the first launch of ramps is repaired by results(): the retry)
+                assert torch.equal(dec.out, px), launch
+            r = dec.results()
+            assert (r["status"] == 0).all() and (r["pad"] == 0).all() and torch.equal(dec.out, px), launch
+            assert bool(dec.shape() & 8) == (not switches), (launch, dec.shape())
+        dec.close()
+        enc.close()
+        for k, _ in env:
+            monkeypatch.delenv(k)
+
+    photo = torch.empty((n, s, s, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(photo, "photo", seed=1, img0=0)
+    mixed = torch.empty((n, s, s, 4), dtype=torch.uint8, device="cuda")
+    sq.synth(mixed, "mixed", seed=1, img0=0)
+    run(photo, True)
+    run(mixed, False)
+    run(ramp, True)
+    run(photo, False, env=(("SQOA_HIP_DEC_CONTENT", "0"),))
+    run(photo, False, env=(("SQOA_HIP_DEC_BAL", "1"),))
+    # most of the pixels decide: 16 photographs among 48 screenshots stay, 48 among 16 switch
+    run(torch.cat([photo[:16], mixed[:48]]), False)
+    run(torch.cat([photo[:48], mixed[:16]]), True)
 
 
 def test_qoi_groups_of_few_index_ops_match_oracle(sq, orc, route):
