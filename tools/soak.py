@@ -43,8 +43,13 @@ for r in range(rounds):
         wants = [o.encode(raw, w, h, ch, mode) for (w, h, ch, raw) in imgs]
         # (the plan's own choices; the chip-wide routes for everything; one workgroup per image with the wave decoder at 8 bytes per
         # lane, at 12, at 12 with the position-major store path, and the balanced kernel wherever a plan's jobs all go to four channels)
-        for strips, passes, wide, sweep, bal in (("", "", "", "", ""), ("1", "1", "", "", ""), ("0", "0", "0", "0", "0"), ("0", "0", "1", "0", "0"), ("0", "0", "1", "1", "0"),
-                                                 ("0", "0", "1", "0", "1")):
+        # (round 6: one of the forcings runs on the order-free QOI-compat kernels, SQOA_HIP_LDS_ORDER=0 -- sqoa_selftest.hip; and every decode plan of up to
+        # 40 images is launched a second time BEHIND results() -- the lazy skip of the stand-by kernels, the content-driven change of kernel -- with the
+        # pixels looked at before results() is asked again)
+        for strips, passes, wide, sweep, bal, lds in (("", "", "", "", "", ""), ("1", "1", "", "", "", ""), ("0", "0", "0", "0", "0", "0"), ("0", "0", "1", "0", "0", ""),
+                                                      ("0", "0", "1", "1", "0", ""), ("0", "0", "1", "0", "1", ""), ("", "", "", "", "", "0")):
+            if lds: os.environ["SQOA_HIP_LDS_ORDER"] = lds
+            else: os.environ.pop("SQOA_HIP_LDS_ORDER", None)
             os.environ["SQOA_HIP_STRIPS"], os.environ["SQOA_HIP_MULTIPASS"] = strips, passes
             os.environ["SQOA_HIP_DEC_WIDE"], os.environ["SQOA_HIP_DEC_SWEEP"], os.environ["SQOA_HIP_DEC_BAL"] = wide, sweep, bal
             images = [(torch.from_numpy(raw).cuda(), sq.Desc(w, h, ch, 0, mode)) for (w, h, ch, raw) in imgs]
@@ -66,6 +71,16 @@ for r in range(rounds):
                     have = dec.out[dec.offsets[k] : dec.offsets[k] + w * h * occ].cpu().numpy()
                     assert dres["status"][k] == 0 and have.tobytes() == want.tobytes(), ("decode", r, mode, passes, wide, sweep, bal, oc, k, imgs[k][:3])
                     checked += 1
+                if n <= 40:
+                    first = dec.out.clone()
+                    dec.out.zero_()
+                    torch.cuda.synchronize()
+                    dec.launch()
+                    torch.cuda.synchronize()
+                    for k, (w, h, ch, _) in enumerate(imgs):   # (image by image: the few bytes between two images are nobody's)
+                        a, b = dec.offsets[k], dec.offsets[k] + w * h * (oc if oc else ch)
+                        assert torch.equal(dec.out[a:b], first[a:b]), ("relaunch behind results()", r, mode, passes, wide, sweep, bal, oc, k)
+                    assert (dec.results()["status"] == 0).all(), ("relaunch", r, mode, oc)
                 dec.close()
             enc.close()
     print(f"round {r}: {n} images ok", flush=True)
