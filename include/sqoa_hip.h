@@ -165,7 +165,8 @@ void *sqoa_hip_plan_stream(sqoa_hip_plan *plan);
 int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 
 /* Diagnostic (tests, tools): the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each -- decode plans: bit 0 many
- * short streams, bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance.
+ * short streams, bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance;
+ * bit 8: the next launch leaves out the kernels behind the wave decoder (no job of the last fully viewed launch needed them: sqoa_hip_plan_results).
  * A decode plan that took the balanced kernel drops it from the launch after sqoa_hip_plan_results has seen, in a full view of a launch's rows,
  * that most of its pixels come from streams that kernel is slow on (two-byte ops throughout: photographs; or more op starts in a chunk than it has
  * slots: ramps, flat images) -- the kernels report what they saw in the rows; SQOA_HIP_DEC_CONTENT=0 in the environment keeps the first choice. */

@@ -817,8 +817,9 @@ int sqoa_hip_plan_launch(sqoa_hip_plan* p, void* stream) {
 void* sqoa_hip_plan_stream(sqoa_hip_plan* p) { return p ? (void*)p->stream : nullptr; }
 
 // Diagnostic: the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each (decode plans; bit 0 many short streams,
-// bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance), -1 for no plan.
-int sqoa_hip_plan_shape(const sqoa_hip_plan* p) { return p ? p->shape : -1; }
+// bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance; bit 8: the next
+// launch leaves the kernels behind the wave decoder out -- the lazy skip), -1 for no plan.
+int sqoa_hip_plan_shape(const sqoa_hip_plan* p) { return p ? (p->shape | ((p->lazy_skip && !p->wave_only) ? 0x100 : 0)) : -1; }
 
 int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");
@@ -830,7 +831,7 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
         bool slow = false, used = false;
         for (int i = 0; i < n; ++i) {
             slow = slow || out[i].status == SQOA_HIP_ST_SLOWPATH;
-            used = used || reinterpret_cast<const unsigned char*>(&out[i].desc)[11] != 0;
+            used = used || (reinterpret_cast<const unsigned char*>(&out[i].desc)[11] & 1u) != 0;   // (bit 0: stand-by used; bits 1..7: the content hint)
         }
         if (slow) {
             // a row still SLOWPATH on a plan that is not WAVEONLY: the launch left the kernels behind the wave decoder out (the lazy skip) and a
