@@ -655,8 +655,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
             }
             if (e == hipSuccess) p->st_strips_cap = ns;
         }
-        // (the per-image ticks of strip_cut_kernel live in d_offsets: zero before the first launch, put back to zero by the kernel itself)
-        if (e == hipSuccess) e = hipMemset(p->st.d_offsets, 0, (ns + 1) * sizeof(unsigned long long));
+
         if (e == hipSuccess) e = grow(&p->st.d_ws, &p->st.ws_bytes, st_ws, 1);
         if (e != hipSuccess) {
             // no memory for the strips' workspace (5 bytes per pixel of the images cut): not an error -- the images stay where they

@@ -8,8 +8,8 @@
 //
 //   strip_cut_kernel   one wave per nominal cut: the first pixel at or behind it that differs from its predecessor, searched
 //                      up to the next nominal cut (none: the stretch is the inside of one run and joins the strip in front);
-//                      the wave that finishes an image's last cut turns the cuts that exist into strip jobs (source stretch,
-//                      flags, a slot of the plan's workspace), the others into skipped rows (id -1);
+//   strip_job_kernel   one wave per image: the cuts that exist become strip jobs (source stretch, flags, a slot of the plan's
+//                      workspace), the others a skipped row (id -1);
 //   encode_kernel      over the strip jobs;
 //   strip_pack_kernel  one workgroup per strip: its stream goes behind the image's header (seqoia.h:497-514) and the streams
 //                      of the strips in front of it (it adds their lengths up itself), at the image's own dst; the first one writes
@@ -34,19 +34,33 @@ constexpr uint32_t ST_NONE = 0xffffffffu;
 SQOA_DEV uint32_t st_nominal(uint32_t npx, uint32_t k, uint32_t s) { return (uint32_t)((unsigned long long)npx * k / s); }
 SQOA_DEV int st_stride(const sqoa_desc& d) { return (d.channels < 3 ? 1 : 3) + ((d.channels & 1) ? 0 : 1); }   // seqoia.h:486
 
-// The strip jobs of one image from its cuts (one wave, lane = strip row modulo 64).  `cuts` is read with agent-scope loads: the words were
-// written by other workgroups of the SAME launch (strip_cut_kernel below), possibly on another XCD.
-SQOA_DEV void strip_build_jobs(const sqoa_hip_job& job, const st_image& im, uint32_t* cuts, sqoa_hip_job* sjobs, int* sids, sqoa_hip_result* sres, int lane) {
+// The strip jobs of one image from its cuts (one wave, lane = strip row modulo 64).  The cuts are copied to LDS first, all loads in flight
+// together: read one by one where they lie, with the search for the next cut that exists, the loop is a chain of L2 round trips.
+constexpr uint32_t ST_CUTS_LDS = 2048;   // = SQOA_ST_WGS (sqoa_runtime.hip): no launch holds more strip rows
+SQOA_DEV void strip_build_jobs(const sqoa_hip_job& job, const st_image& im, const uint32_t* cuts, sqoa_hip_job* sjobs, int* sids, sqoa_hip_result* sres, int lane) {
+    __shared__ uint32_t s_cuts[ST_CUTS_LDS];
     const uint32_t ch = (uint32_t)st_stride(job.desc);
-    auto cut_of = [&](uint32_t row) { return __hip_atomic_load(&cuts[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const bool in_lds = im.nstrips <= ST_CUTS_LDS;
+    if (in_lds) {
+        for (uint32_t k0 = 0; k0 < im.nstrips; k0 += 512) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) { const uint32_t k = k0 + 64u * u + (uint32_t)lane; v[u] = k < im.nstrips ? cuts[im.first + k] : ST_NONE; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) { const uint32_t k = k0 + 64u * u + (uint32_t)lane; if (k < im.nstrips) s_cuts[k] = v[u]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    auto cut_of = [&](uint32_t k) { return in_lds ? s_cuts[k] : cuts[im.first + k]; };
     for (uint32_t k = lane; k < im.nstrips; k += 64) {
-        const uint32_t row = im.first + k, cut = cut_of(row);
+        const uint32_t row = im.first + k, cut = cut_of(k);
         sres[row].len = 0;      // the rows as they must read before the encoder runs (a skipped row stays like this)
         sres[row].status = SQOA_HIP_ST_OK;
         if (cut == ST_NONE) { sids[row] = -1; continue; }
         uint32_t nx = k + 1;
-        while (nx < im.nstrips && cut_of(im.first + nx) == ST_NONE) ++nx;
-        const uint32_t end = nx < im.nstrips ? cut_of(im.first + nx) : im.npx;
+        while (nx < im.nstrips && cut_of(nx) == ST_NONE) ++nx;
+        const uint32_t end = nx < im.nstrips ? cut_of(nx) : im.npx;
         sqoa_hip_job s;
         s.src = job.src + (unsigned long long)cut * ch;
         // slots in the workspace: worst case ch + 1 bytes per pixel (seqoia.h:487-489) behind the strips in front, 256-aligned
@@ -62,13 +76,11 @@ SQOA_DEV void strip_build_jobs(const sqoa_hip_job& job, const st_image& im, uint
     }
 }
 
-// One wave per nominal cut.  Round 6: the wave that finishes LAST of an image's cuts (a tick per image, counted with agent-scope acquire /
-// release atomics: the cuts the others wrote are visible to whoever sees the last tick) builds the image's strip jobs on the spot -- what
-// strip_job_kernel did in a launch of its own, 5 us of a lone image's 50; it puts the tick back to zero for the next launch (`ticks`: one word per
-// image, zero when the plan is filled).
+// One wave per nominal cut.  (Round 6 tried to have the wave that finishes an image's LAST cut build the strip jobs on the spot -- a tick per image
+// counted with agent-scope acquire / release atomics -- to save strip_job_kernel's launch: byte-exact, ten minutes of soak, and SLOWER, 16 us against
+// 4.8 + 5.4 for the two launches: 506 waves releasing through one counter means 506 write-backs of the L2 in a row on a part with eight of them.)
 __global__ __launch_bounds__(64) void strip_cut_kernel(const sqoa_hip_job* __restrict__ jobs, const st_image* __restrict__ images,
-                                                       const st_strip* __restrict__ strips, uint32_t* __restrict__ cuts, uint32_t* __restrict__ ticks,
-                                                       sqoa_hip_job* __restrict__ sjobs, int* __restrict__ sids, sqoa_hip_result* __restrict__ sres) {
+                                                       const st_strip* __restrict__ strips, uint32_t* __restrict__ cuts) {
     const int lane = lane_id();
     const st_strip me = strips[blockIdx.x];
     const st_image im = images[me.img];
@@ -90,15 +102,14 @@ __global__ __launch_bounds__(64) void strip_cut_kernel(const sqoa_hip_job* __res
             if (m) { cut = base + (uint32_t)__builtin_ctzll(m); break; }
         }
     }
-    uint32_t last = 0;
-    if (lane == 0) {
-        __hip_atomic_store(&cuts[im.first + me.k], cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_fetch_add(&ticks[me.img], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == im.nstrips - 1u ? 1u : 0u;
-    }
-    if (!bcast_first(last)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the whole wave: its lanes read the others' cuts)
-    if (lane == 0) __hip_atomic_store(&ticks[me.img], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    strip_build_jobs(job, im, cuts, sjobs, sids, sres, lane);
+    if (lane == 0) cuts[im.first + me.k] = cut;
+}
+
+__global__ __launch_bounds__(64) void strip_job_kernel(const sqoa_hip_job* __restrict__ jobs, const st_image* __restrict__ images,
+                                                       const uint32_t* __restrict__ cuts, sqoa_hip_job* __restrict__ sjobs, int* __restrict__ sids,
+                                                       sqoa_hip_result* __restrict__ sres) {
+    const st_image im = images[blockIdx.x];
+    strip_build_jobs(jobs[im.jid], im, cuts, sjobs, sids, sres, lane_id());
 }
 
 // QOI-compat strips: per slot of the colour index, the last pixel of the strip that differs from its predecessor and hashes to
@@ -250,8 +261,8 @@ extern "C" hipError_t sqoa_launch_encode_strips(const sqoa_hip_job* d_jobs, sqoa
     sqoa_hip_result* sres = (sqoa_hip_result*)st->d_results;
     const int* sids = (const int*)st->d_ids;
     const int ns_q = st->n_strips_qoi, ns_s = st->n_strips - ns_q, ni_q = st->n_images_qoi, ni_s = st->n_images - ni_q;
-    // (`d_offsets`, one 8-byte row per strip + 1: since round 6 the per-image ticks of strip_cut_kernel, zeroed when the plan is filled)
-    hipLaunchKernelGGL(strip_cut_kernel, dim3(st->n_strips), dim3(64), 0, stream, d_jobs, im, ss, (uint32_t*)st->d_cuts, (uint32_t*)st->d_offsets, sjobs, (int*)st->d_ids, sres);
+    hipLaunchKernelGGL(strip_cut_kernel, dim3(st->n_strips), dim3(64), 0, stream, d_jobs, im, ss, (uint32_t*)st->d_cuts);
+    hipLaunchKernelGGL(strip_job_kernel, dim3(st->n_images), dim3(64), 0, stream, d_jobs, im, (const uint32_t*)st->d_cuts, sjobs, (int*)st->d_ids, sres);
     hipError_t e = sqoa_launch_encode_tab(sjobs, sids, ns_s, 0, sres, nullptr, 0, stream);
     if (e != hipSuccess) return e;
     if (ns_q > 0) {

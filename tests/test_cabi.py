@@ -73,6 +73,23 @@ def test_argument_checks_need_no_device():
     assert seqoia_amd.decode(b"Sqob" + b"\0" * 30, 4)[0] is None  # bad magic: rejected on the host
 
 
+def test_lds_order_entry_points_say_no_device_without_one_and_both_kernel_forms_are_in_the_library():
+    """include/sqoa_hip.h: sqoa_hip_lds_order / sqoa_hip_lds_order_probe report "no such device" where there is none (no compute, no fallback), and
+    the ONE library holds both forms of the QOI-compat encoder -- the order-free one as sqoa::fb::encode_kernel (INTEGRATION.md section 6)."""
+    import ctypes as C
+    import torch
+
+    lib = seqoia_amd._lib.load()
+    if not torch.cuda.is_available():
+        out = (C.c_uint * 3)()
+        assert lib.sqoa_hip_lds_order(0) == -1 and lib.sqoa_hip_lds_order_probe(0, out) == -1
+    nm = subprocess.run(["nm", "-C", seqoia_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("sqoa::encode_kernel<8, true>", "sqoa::fb::encode_kernel<8, true>", "sqoa::fb::encode_kernel<4, true>", "sqoa::fb::encode_kernel<1, true>",
+                "sqoa::lds_order_probe_kernel", "sqoa_launch_encode_tab_fb", "sqoa_launch_encode_small_fb"):
+        assert sym in nm, sym
+    assert "sqoa::fb::encode_kernel<8, false>" not in nm   # (the second build holds the QOI-compat kernels only)
+
+
 def test_encode_bound_matches_reference_formula():
     # w*h*(ch+1)+14+8 (seqoia.h:487-489) + 1 start byte (seqoia.h:513), rounded up to 256
     for w, h, c, ch in ((1, 1, 4, 4), (1024, 1024, 4, 4), (64, 64, 3, 3), (10, 10, 5, 3), (10, 10, 6, 4), (7, 3, 1, 1), (7, 3, 2, 2)):
