@@ -129,6 +129,44 @@ __global__ __launch_bounds__(256) void strip_qtab_kernel(const sqoa_hip_job* __r
         const uint32_t n = job.desc.width * job.desc.height;
         // the strip's first pixel: its predecessor is the pixel in front of the strip, or (0,0,0,255) at the image's start (seqoia.h:521-525)
         const uint32_t pv0 = (job.reserved & SQOA_HIP_JOB_PREV) ? load_px(src - ch, 0, ch) : kPxInit;
+        if (ch == 4 && !(job.src & 3ull)) {
+            // four pixels a load (RGBA): a strip starts wherever its cut fell, so the first `head` pixels up to the next 16-byte boundary go one by
+            // one, then quads, four loads in flight; the pixel in front of a quad is the last of the quad before -- one more dword, from a line
+            // the neighbouring thread fetches; the last one to three pixels one by one again
+            constexpr int U4 = 4;
+            gcptr32 s32 = (gcptr32)src;
+            const uint32_t head0 = (uint32_t)((16u - (uint32_t)(job.src & 15ull)) & 15u) >> 2, head = head0 < n ? head0 : n;
+            const uint32_t nq = (n - head) >> 2;
+            auto one = [&](uint32_t p) {
+                const uint32_t px1 = s32[p], pv1 = p ? s32[p - 1u] : pv0;
+                if (px1 != pv1) atomicMax(&s_last[qoi_hash(px1)], (unsigned long long)(p + 1u) << 32 | px1);
+            };
+            if (threadIdx.x < head) one(threadIdx.x);
+            for (uint32_t p = head + (nq << 2) + threadIdx.x; p < n; p += 256u) one(p);
+            gcptr128 q128 = (gcptr128)(s32 + head);
+            for (uint32_t q0 = threadIdx.x; q0 < nq; q0 += 256u * U4) {
+                u32x4 v[U4];
+                uint32_t pq[U4];
+#pragma unroll
+                for (int u = 0; u < U4; ++u) {
+                    const uint32_t qi = q0 + 256u * (uint32_t)u, p = head + 4u * qi;
+                    v[u] = qi < nq ? q128[qi] : u32x4{0u, 0u, 0u, 0u};
+                    pq[u] = qi < nq ? (p ? s32[p - 1u] : pv0) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < U4; ++u) {
+                    const uint32_t qi = q0 + 256u * (uint32_t)u, p = head + 4u * qi;
+                    if (qi >= nq) continue;
+                    const uint32_t px4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    uint32_t prev = pq[u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (px4[i] != prev) atomicMax(&s_last[qoi_hash(px4[i])], (unsigned long long)(p + (uint32_t)i + 1u) << 32 | px4[i]);
+                        prev = px4[i];
+                    }
+                }
+            }
+        } else {
         constexpr int U = 8;
         for (uint32_t p0 = threadIdx.x; p0 < n; p0 += 256u * U) {
             uint32_t px[U], pv[U];
@@ -143,6 +181,7 @@ __global__ __launch_bounds__(256) void strip_qtab_kernel(const sqoa_hip_job* __r
                 const uint32_t p = p0 + 256u * (uint32_t)u;
                 if (p < n && px[u] != pv[u]) atomicMax(&s_last[qoi_hash(px[u])], (unsigned long long)(p + 1u) << 32 | px[u]);
             }
+        }
         }
     }
     __syncthreads();
