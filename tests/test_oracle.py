@@ -151,3 +151,21 @@ def test_c4_and_c5_digest_tables_against_the_restatement():
         if len(seen) >= 11 and all(v >= 2 for v in seen.values()):
             break
     assert len(seen) >= 11
+
+
+def test_lds_conflict_model_reproduces_its_committed_table():
+    """tools/lds_conflict_model.py (the balanced decoder's LDS bank conflicts by access class, on real streams) is an argument
+    the design rests on: it has to keep running, and to keep saying what profiles/r06_lds_conflict_model.txt says -- class mixed in the low
+    200s of conflict cycles a chunk with the transition table's look-ups the largest share, class photo about twice that."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "lds_conflict_model.py"), "1"], capture_output=True, text=True, check=True).stdout
+    sums = [float(m.group(1)) for m in re.finditer(r"sum \(per chunk and wave\)\s+([0-9.]+)", out)]
+    ftab = [float(m.group(1)) for m in re.finditer(r"ftab \(2 passes x 16 reads\)\s+([0-9.]+)", out)]
+    assert len(sums) == 2 and len(ftab) == 2, out
+    assert 180 < sums[0] < 260 and 400 < sums[1] < 520, sums          # class mixed, class photo (the counters: 254 on the headline batch)
+    assert ftab[0] > 0.4 * sums[0], (ftab, sums)                      # data-dependent look-ups are the largest share on class mixed
