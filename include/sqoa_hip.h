@@ -166,10 +166,12 @@ int sqoa_hip_plan_launch(sqoa_hip_plan *plan, void *stream);
 
 /* Diagnostic (tests, tools): the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each -- decode plans: bit 0 many
  * short streams, bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance;
- * bit 8: the next launch leaves out the kernels behind the wave decoder (no job of the last fully viewed launch needed them: sqoa_hip_plan_results).
+ * bit 8: the next launch leaves out the kernels behind the wave decoder (no job of the last fully viewed launch needed them: sqoa_hip_plan_results);
+ * bit 9: a part of the list is launched apart, beside the rest, with a shape of its own (a list of mixed output formats, or of mixed content).
  * A decode plan that took the balanced kernel drops it from the launch after sqoa_hip_plan_results has seen, in a full view of a launch's rows,
  * that most of its pixels come from streams that kernel is slow on (two-byte ops throughout: photographs; or more op starts in a chunk than it has
- * slots: ramps, flat images) -- the kernels report what they saw in the rows; SQOA_HIP_DEC_CONTENT=0 in the environment keeps the first choice. */
+ * slots: ramps, flat images) -- the kernels report what they saw in the rows; where such streams are a twentieth to a half of the pixels they are
+ * split off into a launch of their own beside the others; SQOA_HIP_DEC_CONTENT=0 in the environment keeps the first choice. */
 int sqoa_hip_plan_shape(const sqoa_hip_plan *plan);
 
 /* Wait for the plan's most recent launch and copy the n results to host memory.  This call is what makes a launch's statuses and

@@ -134,6 +134,9 @@ struct sqoa_hip_plan {
     int shape_nobal = 0;                // decode: the shape the same streams get WITHOUT the balanced kernel -- taken from the launch after the one whose result
                                         // rows say that the content is of the kind that kernel is slow on (row_content_hint, sqoa_common.h)
     bool content_switched = false;
+    std::vector<sqoa_hip_job> h_jobs;   // decode: the job table and the id list as uploaded (sqoa_hip_plan_results re-partitions the list by content)
+    std::vector<int> h_ids;
+    int n_multi = 0;                    // decode: the first n_multi ids take the three chip-wide passes
     int n_chain_b = 0, shape_b = 0;     // decode: the last n_chain_b of the streams that get a workgroup each are launched apart, with a shape of their own
                                         // (a plan of mixed output formats: its four-channel streams take the balanced kernel, the others what suits them)
     // decode, the two kernels behind the wave decoder (QOI-compat / mono / 1-2 channels / SQOA_OP_REF): launched with every launch until a launch's
@@ -354,6 +357,41 @@ static int encode_route(const unsigned long long* pixels, int n, int cus, int mo
     return 0;
 }
 
+// Which shape of the wave decoder a part of a decode plan's id list gets (ids[a .. b) of `jobs`): what the plan can see without reading a stream --
+// output channels, image shapes, stream sizes -- and the knobs (plan_fill has the reasons; sqoa_hip_plan_results calls it again when it splits a
+// list by what the launches saw of the content).  bit 0 many short streams, bit 1 twelve stream bytes per lane, bit 2 position-major stores,
+// bit 3 the balanced kernel, bit 4 its three-channel instance.
+static int decode_shape_of(const sqoa_hip_job* jobs, const int* ids, size_t a, size_t b, int small, bool allow_bal) {
+    if (a >= b) return 0;
+    const char* kw = getenv("SQOA_HIP_DEC_WIDE");
+    const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
+    const char* kb = getenv("SQOA_HIP_DEC_BAL");
+    unsigned long long by = 0, by4 = 0, px = 0;
+    bool shaped = true, all4 = true, any3 = false;
+    for (size_t k = a; k < b; ++k) {
+        const sqoa_hip_job& j = jobs[ids[k]];
+        by += j.src_size;
+        px += (unsigned long long)j.desc.width * j.desc.height;
+        if (j.desc.channels == 4) by4 += j.src_size;
+        // what the balanced kernel takes: four channels to a dword-aligned address, or three (round 5: 12-byte stores at any byte address)
+        if (!(j.desc.channels == 3 || (j.desc.channels == 4 && !(j.dst & 3ull)))) all4 = false;
+        if (j.desc.channels != 4) any3 = true;
+        if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
+    }
+    const bool roomy = by / (b - a) >= (12u << 10);
+    int wide = roomy && 4u * by4 >= 3u * by, sweep = shaped && roomy && by < px;
+    if (kw) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
+    if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
+    //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
+    //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
+    //    -- a kernel for four channels to dword-aligned addresses and (its RGB instance, bit 4) for three channels, so only for lists
+    //    whose every job is one of the two; a list to three channels alone keeps the wave decoder (SQOA_DEC_BAL_RGB above)
+    int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !small;
+    if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
+    bal = bal && all4 && allow_bal;
+    return small | wide << 1 | sweep << 2 | bal << 3 | (bal && any3 ? 1 : 0) << 4;   // (bit 4: the balanced kernel's instance that takes three-channel jobs)
+}
+
 // Classify jobs, fill the pre-launch result rows and the per-variant id lists, upload all three.
 static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     std::vector<sqoa_hip_result> init(n ? n : 1);
@@ -503,37 +541,9 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
         // (SQOA_HIP_DEC_WIDE / SQOA_HIP_DEC_SWEEP = 0 / 1 in the environment force either: tests and measurements; the results are the same.)
         {
             const size_t c0 = (size_t)n_multi;
-            const char* kw = getenv("SQOA_HIP_DEC_WIDE");
-            const char* ks = getenv("SQOA_HIP_DEC_SWEEP");
-            const char* kb = getenv("SQOA_HIP_DEC_BAL");
             // what the balanced kernel takes: four channels to a dword-aligned address, or three (round 5: 12-byte stores at any byte address)
             auto four = [&](int i) { return jobs[i].desc.channels == 3 || (jobs[i].desc.channels == 4 && !(jobs[i].dst & 3ull)); };
-            auto shape_of = [&](size_t a, size_t b, bool allow_bal = true) -> int {
-                if (a >= b) return 0;
-                unsigned long long by = 0, by4 = 0, px = 0;
-                bool shaped = true, all4 = true, any3 = false;
-                for (size_t k = a; k < b; ++k) {
-                    const sqoa_hip_job& j = jobs[ids_a[k]];
-                    by += j.src_size;
-                    px += (unsigned long long)j.desc.width * j.desc.height;
-                    if (j.desc.channels == 4) by4 += j.src_size;
-                    if (!four(ids_a[k])) all4 = false;
-                    if (j.desc.channels != 4) any3 = true;
-                    if (!j.desc.width || !j.desc.height || j.desc.channels < 3) shaped = false;
-                }
-                const bool roomy = by / (b - a) >= (12u << 10);
-                int wide = roomy && 4u * by4 >= 3u * by, sweep = shaped && roomy && by < px;
-                if (kw) wide = kw[0] == '1' ? 1 : kw[0] == '0' ? 0 : wide;
-                if (ks) sweep = ks[0] == '1' ? 1 : ks[0] == '0' ? 0 : sweep;
-                //  * the balanced kernel (sqoa_decode_bal.hip: ops dealt out evenly over the lanes, 1024-byte chunks) where the wide shape
-                //    would be picked for streams that are many chunks long and not run-heavy (SQOA_HIP_DEC_BAL = 0 / 1 forces it)
-                //    -- a kernel for four channels to dword-aligned addresses and (its RGB instance, bit 4) for three channels, so only for lists
-                //    whose every job is one of the two; a list to three channels alone keeps the wave decoder (SQOA_DEC_BAL_RGB above)
-                int bal = (wide || (roomy && SQOA_DEC_BAL_RGB && all4)) && !sweep && !p->small;
-                if (kb) bal = kb[0] == '1' ? 1 : kb[0] == '0' ? 0 : bal;
-                bal = bal && all4 && allow_bal;
-                return p->small | wide << 1 | sweep << 2 | bal << 3 | (bal && any3 ? 1 : 0) << 4;   // (bit 4: the balanced kernel's instance that takes three-channel jobs)
-            };
+            auto shape_of = [&](size_t a, size_t b, bool allow_bal = true) -> int { return decode_shape_of(jobs, ids_a.data(), a, b, p->small, allow_bal); };
             p->shape = shape_of(c0, ids_a.size());
             p->shape_nobal = shape_of(c0, ids_a.size(), false);
             p->n_chain_b = 0; p->shape_b = 0;
@@ -574,6 +584,7 @@ static int plan_fill(sqoa_hip_plan* p, const sqoa_hip_job* jobs, int n) {
     p->n_sqoa = (int)ids_a.size();
     p->n_qoi = (int)ids_b.size();
     ids_a.insert(ids_a.end(), ids_b.begin(), ids_b.end());
+    if (p->kind == SQOA_HIP_DECODE) { p->h_jobs.assign(jobs, jobs + n); p->h_ids = ids_a; p->n_multi = n_multi_dec; }
     if (n == 0) return 0;
     hipError_t e;
     if ((e = hipMemcpy(p->d_jobs, jobs, sizeof(sqoa_hip_job) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -819,8 +830,8 @@ void* sqoa_hip_plan_stream(sqoa_hip_plan* p) { return p ? (void*)p->stream : nul
 
 // Diagnostic: the kernel shape the plan's NEXT launch takes for the streams that get a workgroup each (decode plans; bit 0 many short streams,
 // bit 1 twelve stream bytes per lane, bit 2 position-major stores, bit 3 the balanced kernel, bit 4 its three-channel instance; bit 8: the next
-// launch leaves the kernels behind the wave decoder out -- the lazy skip), -1 for no plan.
-int sqoa_hip_plan_shape(const sqoa_hip_plan* p) { return p ? (p->shape | ((p->lazy_skip && !p->wave_only) ? 0x100 : 0)) : -1; }
+// launch leaves the kernels behind the wave decoder out -- the lazy skip; bit 9: a part of the list is launched apart, with a shape of its own), -1 for no plan.
+int sqoa_hip_plan_shape(const sqoa_hip_plan* p) { return p ? (p->shape | ((p->lazy_skip && !p->wave_only) ? 0x100 : 0) | (p->n_chain_b > 0 ? 0x200 : 0)) : -1; }
 
 int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
     if (!p || !out || n < 0 || n > p->n) return fail(SQOA_HIP_EINVAL, "sqoa_hip_plan_results: bad arguments");
@@ -852,17 +863,58 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
         if (n == p->n && (p->shape & 8) && !p->content_switched) {
             const char* kc = getenv("SQOA_HIP_DEC_CONTENT");
             const bool content = !(kc && kc[0] == '0');
+            // (the balanced part of the id list: behind the multi-pass prefix, in front of a part that was split off when the plan was filled)
+            const size_t c0 = (size_t)p->dp.n_images, c1 = (size_t)(p->n_sqoa - p->n_chain_b);
+            auto slow_job = [&](int i) {
+                const unsigned hint = reinterpret_cast<const unsigned char*>(&out[i].desc)[11] >> 1;
+                // (127: the slot overflow.  Jobs to FOUR channels only: what they move to is decode_wave_kernel at twelve bytes a lane with dword
+                // stores; a three-channel job would move to its eight-byte shape with byte stores, and BASELINE configs[4]'s rank shard -- 557
+                // three-channel photographs among 7 635 four-channel images -- decodes in 10.28 ms with them in the balanced kernel's
+                // three-channel instance and in 10.5 ms with them split off: measured, round 6)
+                return hint >= 1u + 448u / 4u && out[i].status == SQOA_HIP_ST_OK && p->h_jobs[i].desc.channels == 4;
+            };
             unsigned long long px_said = 0, px_slow = 0;
-            for (int i = 0; i < n; ++i) {
+            size_t n_slow = 0;
+            for (size_t k = c0; k < c1 && k < p->h_ids.size(); ++k) {
+                const int i = p->h_ids[k];
                 const unsigned hint = reinterpret_cast<const unsigned char*>(&out[i].desc)[11] >> 1;
                 if (!hint || out[i].status != SQOA_HIP_ST_OK) continue;
                 const unsigned long long w = (unsigned long long)out[i].desc.width * out[i].desc.height;
                 px_said += w;
-                if (hint >= 1u + 448u / 4u) px_slow += w;   // (127: the slot overflow)
+                if (slow_job(i)) { px_slow += w; ++n_slow; }
             }
-            if (content && !getenv("SQOA_HIP_DEC_BAL") && px_said && 2 * px_slow >= px_said) {
-                p->shape = p->shape_nobal;
-                p->content_switched = true;
+            if (content && !getenv("SQOA_HIP_DEC_BAL") && px_said && px_slow) {
+                bool whole = 2 * px_slow >= px_said;
+                // A list of BOTH kinds -- a suite of screenshots and photographs: BASELINE configs[4] -- is split the way plan_fill splits a list of mixed
+                // output formats: the streams the balanced kernel is slow on join (or become) the part that is launched beside it, on the plan's side
+                // stream, with the shape THEY get without it.  From a twentieth of the pixels on; below that the second launch is not worth its ramp.
+                // (1 024 x 1 Mpixel RGBA, photographs among screenshots, tools/time_mixed_content.py: 128 photographs 2.63 -> 2.56 ms, 256: 2.61 -> 2.46,
+                // 400: 2.73 -> 2.47.)
+                if (!whole && 20 * px_slow >= px_said && p->side && c1 - c0 - n_slow >= 1) {
+                    std::vector<int> ids = p->h_ids, keep, moved;
+                    for (size_t k = c0; k < c1; ++k) (slow_job(ids[k]) ? moved : keep).push_back(ids[k]);
+                    // (they go BEHIND the ones that stay and IN FRONT of a part that was split off when the plan was filled, which keeps its place:
+                    // a graph captured earlier still launches the balanced kernel over [c0, c1) and finds nothing there it cannot take)
+                    std::copy(keep.begin(), keep.end(), ids.begin() + (long)c0);
+                    std::copy(moved.begin(), moved.end(), ids.begin() + (long)(c0 + keep.size()));
+                    moved.insert(moved.end(), ids.begin() + (long)c1, ids.begin() + p->n_sqoa);
+                    const int sa = decode_shape_of(p->h_jobs.data(), ids.data(), c0, c0 + keep.size(), p->small, true);
+                    if ((sa & 8) && hipMemcpy(p->d_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) == hipSuccess) {
+                        p->h_ids.swap(ids);
+                        p->shape = sa;
+                        p->shape_nobal = decode_shape_of(p->h_jobs.data(), p->h_ids.data(), c0, c0 + keep.size(), p->small, false);
+                        p->shape_b = decode_shape_of(p->h_jobs.data(), p->h_ids.data(), c0 + keep.size(), (size_t)p->n_sqoa, p->small, false);
+                        p->n_chain_b = (int)moved.size();
+                        p->content_switched = true;
+                    } else {
+                        (void)hipGetLastError();
+                        whole = true;   // (what is left would not take the balanced kernel by itself, or the list could not be uploaded: the whole list, then)
+                    }
+                }
+                if (whole && !p->content_switched) {
+                    p->shape = p->shape_nobal;
+                    p->content_switched = true;
+                }
             }
         }
     }

@@ -829,7 +829,7 @@ def test_a_decode_plan_learns_from_the_content_its_launches_see(sq, orc, monkeyp
     row = (x & 255).to(torch.uint8)
     ramp = torch.stack([row, row, row, torch.full_like(row, 255)], dim=-1).expand(n, s, s, 4).contiguous()
 
-    def run(px, switches, env=()):
+    def run(px, switches, env=(), splits=False):
         for k, v in env:
             monkeypatch.setenv(k, v)
         enc = sq.EncodePlan(px, qoi_compat=0)
@@ -848,6 +848,7 @@ def test_a_decode_plan_learns_from_the_content_its_launches_see(sq, orc, monkeyp
             r = dec.results()
             assert (r["status"] == 0).all() and (r["pad"] == 0).all() and torch.equal(dec.out, px), launch
             assert bool(dec.shape() & 8) == (not switches), (launch, dec.shape())
+            assert bool(dec.shape() & 0x200) == splits, (launch, hex(dec.shape()))   # (a part of the list launched apart, beside the rest)
             # (the content hint shares its byte with the "stand-by kernel used" mark: a plan of SQOA colour streams that fit the kernel's slots must
             # still learn that it needs none of the kernels behind -- round 6's first version read the whole byte and launched all three for ever)
             if px is not ramp:
@@ -866,9 +867,35 @@ def test_a_decode_plan_learns_from_the_content_its_launches_see(sq, orc, monkeyp
     run(ramp, True)
     run(photo, False, env=(("SQOA_HIP_DEC_CONTENT", "0"),))
     run(photo, False, env=(("SQOA_HIP_DEC_BAL", "1"),))
-    # most of the pixels decide: 16 photographs among 48 screenshots stay, 48 among 16 switch
-    run(torch.cat([photo[:16], mixed[:48]]), False)
+    # A list of both kinds: from a twentieth of the pixels on the photographs are split off into a launch of their own beside the others (the
+    # balanced kernel keeps the screenshots); from half of the pixels on the whole list changes kernel; two photographs among 62 screenshots stay
+    run(torch.cat([photo[:16], mixed[:48]]), False, splits=True)
     run(torch.cat([photo[:48], mixed[:16]]), True)
+    run(torch.cat([photo[:2], mixed[:62]]), False)
+    run(torch.cat([photo[:16], mixed[:48]]), False, env=(("SQOA_HIP_DEC_CONTENT", "0"),))
+    # ... and the shape of BASELINE configs[4]: three-channel photographs among four-channel screenshots, one list.  They STAY in the balanced kernel's
+    # three-channel instance (what a three-channel job would move to stores bytes: measured slower on that suite, sqoa_runtime.hip)
+    o = orc.best()
+    imgs = [(photo[k, ..., :3].contiguous(), 3) for k in range(16)] + [(mixed[k], 4) for k in range(48)]
+    enc = sq.EncodeList([(t.reshape(-1), sq.Desc(s, s, ch, 0, 0)) for t, ch in imgs])
+    enc.launch()
+    res = enc.results()
+    assert (res["status"] == 0).all()
+    base = enc.out.data_ptr()
+    dec = sq.DecodeList([(base + enc.offsets[k], int(res["len"][k]), s, s, ch) for k, (_, ch) in enumerate(imgs)])
+    assert dec.shape() & 8 and dec.shape() & 16 and not dec.shape() & 0x200
+    for launch in range(3):
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        dec.launch()
+        torch.cuda.synchronize()
+        for k, (t, ch) in enumerate(imgs):
+            assert torch.equal(dec.image(k), t.reshape(-1)), (launch, k)
+        assert (dec.results()["status"] == 0).all()
+        assert dec.shape() & 8 and dec.shape() & 16 and not dec.shape() & 0x200, (launch, hex(dec.shape()))
+    assert dec.image(3).cpu().numpy().tobytes() == o.decode(enc.streams()[3], 3)[0].tobytes()
+    dec.close()
+    enc.close()
 
 
 def test_qoi_groups_of_few_index_ops_match_oracle(sq, orc, route):
