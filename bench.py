@@ -263,11 +263,13 @@ def cpu_baseline(width, height, channels):
 class Uniform:
     """n same-shaped images in one tensor: EncodePlan -> DecodePlan."""
 
-    def __init__(self, sq, torch, dev, n, w, h, ch, cls, img0, qoi=0, check=True):
+    def __init__(self, sq, torch, dev, n, w, h, ch, cls, img0, qoi=0, check=True, blend=None):
         self.n, self.pixels = n, n * w * h
         self.read_bytes = self.pixels * ch
         self.px = torch.empty((n, h, w, ch), dtype=torch.uint8, device=dev)
         sq.synth(self.px, cls, seed=1, img0=img0)
+        if blend:   # (the first `blend[0]` images of another class: a list of mixed content)
+            sq.synth(self.px[: blend[0]], blend[1], seed=1, img0=img0)
         self.enc = sq.EncodePlan(self.px, qoi_compat=qoi)
         self.enc.launch()
         res = self.enc.results()
@@ -454,6 +456,8 @@ def secondary(sq, torch, dev, headline, k=5):
     # photograph usually is -- as RGB decoded to its own three channels and, as sqoabench's timed decode asks (sqoabench.c:490-494), to four
     row(f"class photo {n} x {ww}x{hh} RGBA, qoi_compat=0", Uniform(sq, torch, dev, n, ww, hh, 4, "photo", 0))
     row(f"class photo {n} x {ww}x{hh} RGB, qoi_compat=0", Uniform(sq, torch, dev, n, ww, hh, 3, "photo", 0), four=True)
+    # a list of BOTH kinds (a quarter photographs): the plan splits the photographs off into a launch of their own beside the balanced kernel's
+    row(f"{n // 4} class photo among {n - n // 4} class mixed, {ww}x{hh} RGBA, qoi_compat=0", Uniform(sq, torch, dev, n, ww, hh, 4, "mixed", 0, blend=(n // 4, "photo")))
     for size in (512, 64):
         for qoi in (0, 1):
             row(f"C4 icons 4096 x {size}x{size} RGB, qoi_compat={qoi}", Uniform(sq, torch, dev, 4096, size, size, 3, "icon", 0, qoi=qoi), four=True)
