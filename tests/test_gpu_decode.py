@@ -873,6 +873,32 @@ def test_a_decode_plan_learns_from_the_content_its_launches_see(sq, orc, monkeyp
     run(torch.cat([photo[:48], mixed[:16]]), True)
     run(torch.cat([photo[:2], mixed[:62]]), False)
     run(torch.cat([photo[:16], mixed[:48]]), False, env=(("SQOA_HIP_DEC_CONTENT", "0"),))
+    # a split plan in a graph: the launch beside the balanced kernel's is forked from and joined to the capturing stream by two events
+    px = torch.cat([photo[:16], mixed[:48]])
+    enc = sq.EncodePlan(px, qoi_compat=0)
+    enc.launch()
+    res = enc.results()
+    dec = sq.DecodePlan(enc.out, res["len"], s, s, 4)
+    dec.launch()
+    assert (dec.results()["status"] == 0).all() and dec.shape() & 0x200
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dec.launch(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        dec.launch(side.cuda_stream)
+    for _ in range(2):
+        dec.out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dec.out, px)
+        assert (dec.results()["status"] == 0).all()
+    dec.close()
+    enc.close()
     # ... and the shape of BASELINE configs[4]: three-channel photographs among four-channel screenshots, one list.  They STAY in the balanced kernel's
     # three-channel instance (what a three-channel job would move to stores bytes: measured slower on that suite, sqoa_runtime.hip)
     o = orc.best()
