@@ -883,7 +883,9 @@ int sqoa_hip_plan_results(sqoa_hip_plan* p, sqoa_hip_result* out, int n) {
                 px_said += w;
                 if (slow_job(i)) { px_slow += w; ++n_slow; }
             }
-            if (content && !getenv("SQOA_HIP_DEC_BAL") && px_said && px_slow) {
+            const char* kb = getenv("SQOA_HIP_DEC_BAL");
+            const bool forced = kb && (kb[0] == '0' || kb[0] == '1');   // (as decode_shape_of reads it: set to anything else is not set)
+            if (content && !forced && px_said && px_slow) {
                 bool whole = 2 * px_slow >= px_said;
                 // A list of BOTH kinds -- a suite of screenshots and photographs: BASELINE configs[4] -- is split the way plan_fill splits a list of mixed
                 // output formats: the streams the balanced kernel is slow on join (or become) the part that is launched beside it, on the plan's side
