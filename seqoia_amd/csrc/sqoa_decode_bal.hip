@@ -267,23 +267,36 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #ifndef SQOA_BAL_PREFETCH_LATE
 #define SQOA_BAL_PREFETCH_LATE 0   // (held from the top of the chunk to the end of its walk: 2.625 ms; from the end of the walk to the end of the chunk: 2.662)
 #endif
+        const uint32_t gs = p0 + c * CHUNK;               // stream offset of chunk byte 0
+#ifndef SQOA_BAL_QD_REG   // 1: a lane's 16 bytes for the parse from the registers the chunk was fetched into (they still hold it: the next fetch is issued
+#define SQOA_BAL_QD_REG 0 //    below), the dword behind them from the lane above by one DPP move -- not read back from the LDS copy the walk needs
+#endif
+        uint32_t qd[LB / 4];
+#if SQOA_BAL_QD_REG && !SQOA_BAL_PREFETCH_LATE
+        {
+            const uint32_t nx = shift_down1(stg4.x, bcast_lane(stg1, 0));   // (lane 63: the chunk's dword 256, which lane 0 fetched)
+            const uint32_t dw[LB / 4 + 1] = {stg4.x, stg4.y, stg4.z, stg4.w, nx};
+#pragma unroll
+            for (int k = 0; k < LB / 4; ++k) qd[k] = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], gs & 3u);
+        }
+#endif
 #if !SQOA_BAL_PREFETCH_LATE
         if (more) load_chunk(c + W);
 #endif
-        const uint32_t gs = p0 + c * CHUNK;               // stream offset of chunk byte 0
         const bool last_chunk = IN ? false : c == nchunks - 1;
         const uint32_t my0 = gs + LB * lane;
         const uint32_t nlive = IN ? (uint32_t)LB : my0 >= chunks_len ? 0u : (chunks_len - my0 > (uint32_t)LB ? (uint32_t)LB : chunks_len - my0);
         const uint32_t live_end = IN ? (uint32_t)CHUNK : (chunks_len - gs > (uint32_t)CHUNK ? (uint32_t)CHUNK : chunks_len - gs);   // chunk bytes inside the area
 
         // ---- 1. parse: each lane composes the transition functions of its 16 bytes, one wave scan ----
-        uint32_t qd[LB / 4];
+#if !(SQOA_BAL_QD_REG && !SQOA_BAL_PREFETCH_LATE)
         {   // my 16 bytes start (gs & 3) bytes into dword 4 * lane of the wave's buffer: one 16-byte read, one dword, four v_alignbyte_b32
             const u32x4 a = *reinterpret_cast<const u32x4*>(lds + 4 * lane);
             const uint32_t dw[LB / 4 + 1] = {a.x, a.y, a.z, a.w, lds[4 * lane + 4]};
 #pragma unroll
             for (int k = 0; k < LB / 4; ++k) qd[k] = __builtin_amdgcn_alignbyte(dw[k + 1], dw[k], gs & 3u);
         }
+#endif
         // (the 16 table reads are issued together and waited for once -- the empty asm wants all of them in registers; left to itself
         // the scheduler, at this kernel's register pressure, made it one LDS round trip per byte)
         uint32_t flo[LB];
@@ -298,6 +311,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #if SQOA_BAL_PARSE_BATCH
         asm volatile("" : "+v"(flo[0]), "+v"(flo[1]), "+v"(flo[2]), "+v"(flo[3]), "+v"(flo[4]), "+v"(flo[5]), "+v"(flo[6]), "+v"(flo[7]));
         asm volatile("" : "+v"(flo[8]), "+v"(flo[9]), "+v"(flo[10]), "+v"(flo[11]), "+v"(flo[12]), "+v"(flo[13]), "+v"(flo[14]), "+v"(flo[15]));
+#endif
+#ifndef SQOA_BAL_FLO_REG   // 1: the sixteen entries stay in registers for the starts pass; 0: that pass looks them up in s_ftab again (rounds 5 and 6)
+#define SQOA_BAL_FLO_REG 1
 #endif
         Fn F{ID_LO, ID_HI};
 #pragma unroll
@@ -329,10 +345,22 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
         // ---- 2. starts: the parser state in front of every byte of mine, the op starts among them, their ranks, the list ----
         const uint32_t lst = apply_perm(Fx, st_in);
+#if SQOA_BAL_FLO_REG
+        // The parse's sixteen function entries are still in their registers: between the parse and the walk nothing else wants them (the walk's
+        // op records are not alive yet; 64 VGPRs, no spill), and what the second look-up cost was never the instruction but the LDS pipe this
+        // kernel is bound by -- sixteen data-dependent ds_read_b32 a lane, 50 of the chunk's 219 modelled bank-conflict cycles.  Same call,
+        // headline batch: looked up again 2.550 ms; twelve parked in the wave's list region as three 16-byte pieces and four looked up 2.504;
+        // twelve parked and four in registers 2.472; eight / four parked 2.448 / 2.429; all sixteen in registers 2.403 (-5.8 %).  (The parse's
+        // OWN look-ups through the vector cache instead, from a copy of the table in memory: 2.87 ms -- the wait for them is a wait for the
+        // stores of the chunk before.)  The empty asm pins them: the compiler may not look them up again either.
+#pragma unroll
+        for (int k = 0; k < LB; ++k) asm volatile("" : "+v"(flo[k]));
+#else
         // (my 16 bytes, opaque to the compiler from here on: it would otherwise keep the parse's 16 table addresses in registers across the
         // scan and the chain wait -- and spill the walk's op records for them; recomputing them is one instruction each)
 #pragma unroll
         for (int k = 0; k < LB / 4; ++k) asm volatile("" : "+v"(qd[k]));
+#endif
         uint32_t M;   // bit k: an op (a walk iteration) starts at my byte k
 #ifdef SQOA_DBG_BAL_NOSTARTS
         M = 0x1111u; asm volatile("" : "+v"(M));
@@ -344,14 +372,19 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         {
             uint32_t nxt[LB / 4];   // byte i of word w: the state BEHIND my byte 4 w + i
             uint32_t st = lst;
+            [[maybe_unused]] const uint32_t (&flo_p1)[LB] = flo;   // (the parse's entries: the loop below has a `flo` of its own)
 #pragma unroll
             for (int wd = 0; wd < LB / 4; ++wd) {
                 uint32_t o[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = 4 * wd + i;
+#if SQOA_BAL_FLO_REG
+                    const uint32_t flo = flo_p1[k];
+#else
                     const uint32_t b = (qd[wd] >> (8 * i)) & 0xffu;
                     const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : F_DEAD;
+#endif
                     if (!IN) trouble |= ((st & 0xffu) == (uint32_t)S_G && flo == (1u | 0u << 8 | 3u << 16 | 3u << 24)) ? 1u : 0u;   // an ALPHA byte behind a RUN that was taken along
                     st = __builtin_amdgcn_perm(F_HI, flo, st);   // (byte 0; the other bytes are states too, of no interest)
                     o[i] = st;

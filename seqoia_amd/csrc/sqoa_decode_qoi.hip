@@ -682,10 +682,25 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         uint32_t M;   // bit k: an op starts at my byte k
         {
             uint32_t st = lst, o[QK_LB - 1];
+#ifndef SQOA_QDEC_FLO_REG   // 1: the parse's function entries stay in registers for this pass; 0: looked up in s_ftab again (round 5)
+#define SQOA_QDEC_FLO_REG 1
+#endif
+            // (as in sqoa_decode_bal.hip: the second look-up was seven data-dependent ds_read_b32 a lane into an LDS pipe both sides of this
+            // workgroup wait for; 60 VGPRs, no spill, and seven SGPR spills fewer.  Same call, headline batch: 7.189 -> 6.886 ms, class photo
+            // 5.49 -> 5.34; the entries' low bytes -- an entry is v | v << 8 | 0x02000000 -- packed into two registers and unpacked by one
+            // v_perm_b32 each: 7.036.  The four-wave instance (many short streams: icons 4096 x 512^2, 22 INDEX ops a group, the resolver's
+            // business) measured 2.037 -> 2.063 ms with it and keeps the look-up.)
+            constexpr bool FLO_REG = SQOA_QDEC_FLO_REG && W == 8;
+            if constexpr (FLO_REG) {
+#pragma unroll
+                for (int k = 0; k < QK_LB - 1; ++k) asm volatile("" : "+v"(pflo[k]));
+            }
 #pragma unroll
             for (int k = 0; k < QK_LB - 1; ++k) {
                 const uint32_t b = (uint32_t)(own >> (8 * k)) & 0xffu;
-                const uint32_t flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
+                uint32_t flo;
+                if constexpr (FLO_REG) flo = pflo[k];
+                else flo = (uint32_t)k < nlive ? s_ftab[b] : (ST_X | ST_X << 8 | 0x02000000u);
                 st = __builtin_amdgcn_perm(0x07060403u, flo, st);   // (byte 0: the state behind byte k)
                 o[k] = st;
             }
