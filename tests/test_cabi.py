@@ -194,3 +194,34 @@ def test_no_kernel_restores_exec_from_exec(tmp_path):
         bad = [l for l in text.splitlines() if re.search(r"s_mov_b64\s+exec,\s*exec\b", l)]
         assert not bad, (o, bad[:3])
     assert kernels >= 10, kernels
+
+
+def test_decoders_that_keep_the_parse_entries_in_registers_do_not_spill(tmp_path):
+    """The balanced SQOA decoder and the eight-wave QOI-compat decoder keep the parse's transition-table entries in VGPRs for the starts pass
+    instead of looking them up in LDS a second time (round 6) -- on the understanding that nothing else wants those
+    registers there.  The code objects' notes say whether that still holds with this compiler: no VGPR spill in the four-channel balanced
+    kernel and in the eight-wave QOI-compat instances, eight waves a SIMD (at most 64 VGPRs), and a workgroup's LDS within a quarter of a CU's."""
+    import glob
+    import shutil
+
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        import pytest
+
+        pytest.skip("no llvm-objdump / llvm-readelf in this image")
+    lib = shutil.copy(seqoia_amd._lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    found = {}
+    for o in glob.glob(str(tmp_path / "lib.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", o], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            get = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))
+            found[name.group(1)] = (get("vgpr_count"), get("vgpr_spill_count"), get("group_segment_fixed_size"))
+    bal = [v for k, v in found.items() if "decode_bal_kernelILi8ELi16ELb0EEE" in k]
+    qoi8 = [v for k, v in found.items() if re.search(r"sqoa16?\d*decode_qoi_kernelILi8E", k) or "decode_qoi_kernelILi8E" in k]
+    assert len(bal) == 1 and len(qoi8) >= 2, sorted(found)
+    for vgpr, spill, lds in bal + qoi8:
+        assert spill == 0 and vgpr <= 64 and lds <= 160 * 1024 // 4, (vgpr, spill, lds)
