@@ -269,8 +269,9 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #endif
         const uint32_t gs = p0 + c * CHUNK;               // stream offset of chunk byte 0
 #ifndef SQOA_BAL_QD_REG   // 1: a lane's 16 bytes for the parse from the registers the chunk was fetched into (they still hold it: the next fetch is issued
-#define SQOA_BAL_QD_REG 0 //    below), the dword behind them from the lane above by one DPP move -- not read back from the LDS copy the walk needs
-#endif
+#define SQOA_BAL_QD_REG 0 //    below), the dword behind them from the lane above by one DPP move -- not read back from the LDS copy the walk needs.
+#endif                    //    Built, byte-exact (the decode suite), measured in round 6 and NOT taken: 2.416 -> 2.431 ms -- an aligned ds_read_b128 that
+                          //    every lane issues at its own 16 bytes is not what this kernel waits for; the data-dependent look-ups are (SQOA_BAL_FLO_REG).
         uint32_t qd[LB / 4];
 #if SQOA_BAL_QD_REG && !SQOA_BAL_PREFETCH_LATE
         {
